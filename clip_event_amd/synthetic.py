@@ -1,0 +1,65 @@
+"""Seeded synthetic inputs of the shapes BASELINE.json names.
+
+numpy ``Generator`` streams (PCG64) are used throughout so that the same seed
+gives the same bytes on the build container and on the GPU box.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+ASCII_CAPTIONS: Tuple[str, ...] = (
+    "a photo of a cat",
+    "Protesters march through the streets of the capital on Saturday.",
+    "A soldier is transported to a hospital after an attack near the border.",
+    "The president speaks to reporters at the White House in Washington.",
+    "Rescue workers search for survivors after the earthquake destroyed buildings.",
+    "Police officers arrest a man during a demonstration in the city centre.",
+    "Voters cast their ballots at a polling station during the election.",
+    "Firefighters try to extinguish a fire at a warehouse.",
+)
+
+
+def synthetic_images(batch: int, resolution: int = 224, seed: int = 999) -> torch.Tensor:
+    """N(0,1) images [B,3,R,R] fp32: the statistics after ``Normalize`` (clip.py:62-69)."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.standard_normal((batch, 3, resolution, resolution), dtype=np.float32))
+
+
+def synthetic_tokens(n: int, context_length: int = 77, vocab_size: int = 49408, seed: int = 999,
+                     min_len: int = 8, max_len: Optional[int] = None) -> torch.Tensor:
+    """Token rows as ``clip.tokenize`` lays them out (clip.py:187-199): SOT =
+    vocab-2, ``len`` ids in [1, vocab-3], EOT = vocab-1 (the row maximum, which
+    ``argmax`` relies on, model_clip.py:415), zero padding."""
+    rng = np.random.default_rng(seed)
+    max_len = context_length - 2 if max_len is None else max_len
+    min_len = min(min_len, max_len)
+    out = np.zeros((n, context_length), dtype=np.int64)
+    lens = rng.integers(min_len, max_len + 1, size=n)
+    for i, ln in enumerate(lens):
+        out[i, 0] = vocab_size - 2
+        out[i, 1:1 + ln] = rng.integers(1, vocab_size - 2, size=ln)
+        out[i, 1 + ln] = vocab_size - 1
+    return torch.from_numpy(out)
+
+
+def synthetic_bboxes(batch: int, seed: int = 999, max_roles: int = 4, none_frac: float = 0.25):
+    """Per image a list of 1..max_roles boxes ``(x0,y0,x1,y1)`` in [0,1] or ``None``
+    (input format of the ``train_arg`` branch, dataset_sr.py:159-168)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(batch):
+        n = int(rng.integers(1, max_roles + 1))
+        boxes = []
+        for _ in range(n):
+            if rng.random() < none_frac:
+                boxes.append(None)
+                continue
+            xs = np.sort(rng.random(2))
+            ys = np.sort(rng.random(2))
+            # keep boxes non-degenerate: at least a sliver wide
+            boxes.append((float(xs[0]), float(ys[0]), float(min(1.0, xs[1] + 1e-3)), float(min(1.0, ys[1] + 1e-3))))
+        out.append(boxes)
+    return out

@@ -1,0 +1,512 @@
+"""Plain-PyTorch fp32 restatement of the CLIP-Event model + losses (CPU oracle).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
+
+Functional style: parameters are a flat ``dict`` keyed by the reference's
+state-dict names; every function cites the reference
+``file:line`` (relative to ``/root/reference/src/clip-event``) it restates.
+Activations use the batch-first NLD layout; the reference's LND permutes
+(model_clip.py:247-249, :404-408) are layout-only and do not change values.
+
+``bf16=True`` emulates the rounding points of the HIP path (bf16 GEMM
+operands, fp32 accumulation, fp32 residual stream, fp32 LayerNorm/softmax) so
+that the forward of the device path can be checked with a tight tolerance.
+With ``bf16=False`` this is the reference's fp32 arithmetic, pinned by
+``tests/golden``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class ClipConfig:
+    """Constructor arguments of ``CLIP`` (model_clip.py:267-286), ViT towers only."""
+    embed_dim: int
+    image_resolution: int
+    vision_layers: int
+    vision_width: int
+    vision_patch_size: int
+    context_length: int
+    vocab_size: int
+    transformer_width: int
+    transformer_heads: int
+    transformer_layers: int
+
+    @property
+    def vision_heads(self) -> int:  # model_clip.py:307
+        return self.vision_width // 64
+
+    @property
+    def grid(self) -> int:  # model_clip.py:223
+        return self.image_resolution // self.vision_patch_size
+
+    @property
+    def vision_tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+
+VIT_B32 = ClipConfig(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12)
+VIT_L14_336 = ClipConfig(768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12)
+
+
+def config_from_state_dict(sd: Dict[str, torch.Tensor]) -> ClipConfig:
+    """Shape inference of ``build_model`` (model_clip.py:578-601), ViT branch."""
+    vw = sd["visual.conv1.weight"].shape[0]
+    vl = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    ps = sd["visual.conv1.weight"].shape[-1]
+    grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    tw = sd["ln_final.weight"].shape[0]
+    tl = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
+    return ClipConfig(sd["text_projection"].shape[1], ps * grid, vl, vw, ps,
+                      sd["positional_embedding"].shape[0], sd["token_embedding.weight"].shape[0],
+                      tw, tw // 64, tl)
+
+
+def param_shapes(cfg: ClipConfig) -> "Dict[str, Tuple[int, ...]]":
+    """State-dict keys and shapes in the reference's registration order
+    (model_clip.py:215-230, :171-183, :317-330; probed list in SURVEY.md 8(b))."""
+    shapes: Dict[str, Tuple[int, ...]] = {}
+
+    def block(prefix: str, d: int):
+        shapes[prefix + "attn.in_proj_weight"] = (3 * d, d)
+        shapes[prefix + "attn.in_proj_bias"] = (3 * d,)
+        shapes[prefix + "attn.out_proj.weight"] = (d, d)
+        shapes[prefix + "attn.out_proj.bias"] = (d,)
+        shapes[prefix + "ln_1.weight"] = (d,)
+        shapes[prefix + "ln_1.bias"] = (d,)
+        shapes[prefix + "mlp.c_fc.weight"] = (4 * d, d)
+        shapes[prefix + "mlp.c_fc.bias"] = (4 * d,)
+        shapes[prefix + "mlp.c_proj.weight"] = (d, 4 * d)
+        shapes[prefix + "mlp.c_proj.bias"] = (d,)
+        shapes[prefix + "ln_2.weight"] = (d,)
+        shapes[prefix + "ln_2.bias"] = (d,)
+
+    vw, tw = cfg.vision_width, cfg.transformer_width
+    shapes["positional_embedding"] = (cfg.context_length, tw)
+    shapes["text_projection"] = (tw, cfg.embed_dim)
+    shapes["logit_scale"] = ()
+    shapes["visual.class_embedding"] = (vw,)
+    shapes["visual.positional_embedding"] = (cfg.vision_tokens, vw)
+    shapes["visual.proj"] = (vw, cfg.embed_dim)
+    shapes["visual.conv1.weight"] = (vw, 3, cfg.vision_patch_size, cfg.vision_patch_size)
+    shapes["visual.ln_pre.weight"] = (vw,)
+    shapes["visual.ln_pre.bias"] = (vw,)
+    for i in range(cfg.vision_layers):
+        block(f"visual.transformer.resblocks.{i}.", vw)
+    shapes["visual.ln_post.weight"] = (vw,)
+    shapes["visual.ln_post.bias"] = (vw,)
+    for i in range(cfg.transformer_layers):
+        block(f"transformer.resblocks.{i}.", tw)
+    shapes["token_embedding.weight"] = (cfg.vocab_size, tw)
+    shapes["ln_final.weight"] = (tw,)
+    shapes["ln_final.bias"] = (tw,)
+    return shapes
+
+
+def init_params(cfg: ClipConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Deterministic synthetic state dict with the reference's init scales
+    (model_clip.py:221-230, :348-375).  The *values* are this project's own
+    draw (one CPU generator, keys in ``param_shapes`` order) so that the same
+    weights can be regenerated on any box; they are loaded into the imported
+    reference via ``load_state_dict`` when goldens are captured.  Biases and
+    LayerNorm affine parameters get small random values (instead of the 0/1
+    defaults) so that parity tests exercise them."""
+    rng = np.random.default_rng(seed)
+
+    # numpy Generator streams are stable across boxes and torch builds
+    def randn(shape):
+        return torch.from_numpy(rng.standard_normal(tuple(shape), dtype=np.float32)).to(dtype)
+
+    p: Dict[str, torch.Tensor] = {}
+    tw, tl = cfg.transformer_width, cfg.transformer_layers
+    for name, shape in param_shapes(cfg).items():
+        d = cfg.vision_width if name.startswith("visual.") else tw
+        layers = cfg.vision_layers if name.startswith("visual.") else tl
+        if name == "logit_scale":
+            t = torch.tensor(math.log(1 / 0.07), dtype=dtype)
+        elif name.endswith("ln_1.weight") or name.endswith("ln_2.weight") or name in (
+                "visual.ln_pre.weight", "visual.ln_post.weight", "ln_final.weight"):
+            t = 1.0 + 0.1 * randn(shape)
+        elif name.endswith(".bias") or name.endswith("in_proj_bias"):
+            t = 0.02 * randn(shape)
+        elif name == "token_embedding.weight":
+            t = 0.02 * randn(shape)
+        elif name == "positional_embedding":
+            t = 0.01 * randn(shape)
+        elif name.endswith("in_proj_weight"):
+            t = (d ** -0.5) * randn(shape)
+        elif name.endswith("out_proj.weight") or name.endswith("c_proj.weight"):
+            t = (d ** -0.5) * ((2 * layers) ** -0.5) * randn(shape)
+        elif name.endswith("c_fc.weight"):
+            t = ((2 * d) ** -0.5) * randn(shape)
+        elif name == "text_projection":
+            t = (tw ** -0.5) * randn(shape)
+        elif name in ("visual.class_embedding", "visual.positional_embedding", "visual.proj"):
+            t = (cfg.vision_width ** -0.5) * randn(shape)
+        elif name == "visual.conv1.weight":
+            fan_in = 3 * cfg.vision_patch_size ** 2
+            t = (fan_in ** -0.5) * randn(shape)
+        else:  # pragma: no cover
+            raise KeyError(name)
+        p[name] = t
+    return p
+
+
+# --------------------------------------------------------------------------- helpers
+
+def _r(x: torch.Tensor, bf16: bool) -> torch.Tensor:
+    """Round to bf16 and back (a GEMM-operand rounding point of the HIP path)."""
+    return x.to(torch.bfloat16).to(torch.float32) if bf16 else x
+
+
+def layer_norm(x, w, b, eps: float = 1e-5):
+    """``LayerNorm`` fp32-internal (model_clip.py:157-163); eps = nn default 1e-5."""
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps)
+
+
+def quick_gelu(x):
+    """model_clip.py:166-168."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def build_attention_mask(context_length: int) -> torch.Tensor:
+    """Additive causal mask, -inf strictly above the diagonal (model_clip.py:377-384)."""
+    m = torch.full((context_length, context_length), float("-inf"))
+    return torch.triu(m, diagonal=1)
+
+
+def attention(x_ln, p, prefix: str, heads: int, mask: Optional[torch.Tensor], bf16: bool):
+    """``nn.MultiheadAttention(d, h)`` self-attention, need_weights=False
+    (model_clip.py:175, :185-188): packed in-proj rows [q;k;v], 1/sqrt(head_dim)
+    scaling of q, additive mask, softmax over keys, out-proj."""
+    B, L, D = x_ln.shape
+    hd = D // heads
+    w_in, b_in = p[prefix + "attn.in_proj_weight"], p[prefix + "attn.in_proj_bias"]
+    qkv = _r(_r(x_ln, bf16) @ _r(w_in, bf16).t() + b_in, bf16)          # [B,L,3D]
+    q, k, v = qkv.split(D, dim=-1)
+    q = q.view(B, L, heads, hd).transpose(1, 2)
+    k = k.view(B, L, heads, hd).transpose(1, 2)
+    v = v.view(B, L, heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
+    if mask is not None:
+        s = s + mask
+    a = torch.softmax(s, dim=-1)
+    o = _r(_r(a, bf16) @ v, bf16)                                       # [B,H,L,hd]
+    o = o.transpose(1, 2).reshape(B, L, D)
+    return o @ _r(p[prefix + "attn.out_proj.weight"], bf16).t() + p[prefix + "attn.out_proj.bias"]
+
+
+def residual_block(x, p, prefix: str, heads: int, mask, bf16: bool = False):
+    """``ResidualAttentionBlock.forward`` (model_clip.py:190-200)."""
+    x = x + attention(layer_norm(x, p[prefix + "ln_1.weight"], p[prefix + "ln_1.bias"]),
+                      p, prefix, heads, mask, bf16)
+    h = _r(layer_norm(x, p[prefix + "ln_2.weight"], p[prefix + "ln_2.bias"]), bf16)
+    a = h @ _r(p[prefix + "mlp.c_fc.weight"], bf16).t() + p[prefix + "mlp.c_fc.bias"]
+    g = _r(quick_gelu(a), bf16)
+    x = x + (g @ _r(p[prefix + "mlp.c_proj.weight"], bf16).t() + p[prefix + "mlp.c_proj.bias"])
+    return x
+
+
+def encode_image(p, cfg: ClipConfig, image, use_grid: bool = False, bf16: bool = False):
+    """``VisualTransformer.forward`` (model_clip.py:232-263).  The stride=kernel
+    conv (:219,:235) is restated as the patch GEMM it is; class token + zeros
+    (:240), positional add (:242), ln_pre (:244), blocks (:248), ln_post on the
+    CLS row or on all rows (:253-256), projection (:259-260)."""
+    B = image.shape[0]
+    ps, g, vw = cfg.vision_patch_size, cfg.grid, cfg.vision_width
+    x = image.float().reshape(B, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * ps * ps)
+    x = _r(x, bf16) @ _r(p["visual.conv1.weight"].reshape(vw, -1), bf16).t()   # [B,g*g,vw]
+    cls = p["visual.class_embedding"].expand(B, 1, vw)
+    x = torch.cat([cls, x], dim=1) + p["visual.positional_embedding"]
+    x = layer_norm(x, p["visual.ln_pre.weight"], p["visual.ln_pre.bias"])
+    for i in range(cfg.vision_layers):
+        x = residual_block(x, p, f"visual.transformer.resblocks.{i}.", cfg.vision_heads, None, bf16)
+    x = x if use_grid else x[:, 0, :]
+    x = layer_norm(x, p["visual.ln_post.weight"], p["visual.ln_post.bias"])
+    return _r(x, bf16) @ _r(p["visual.proj"], bf16)
+
+
+def eot_index(text: torch.Tensor) -> torch.Tensor:
+    """``text.argmax(dim=-1)`` (model_clip.py:415): first index of the row maximum."""
+    return text.argmax(dim=-1)
+
+
+def encode_text(p, cfg: ClipConfig, text, bf16: bool = False):
+    """``CLIP.encode_text`` (model_clip.py:398-417): embedding gather (:400),
+    positional add (:403), causal blocks (:406), ln_final (:409), EOT-row gather
+    by argmax and text projection (:415).  LN is per-row, so normalising only
+    the gathered row is identical to :409 followed by :415."""
+    x = p["token_embedding.weight"][text] + p["positional_embedding"]
+    mask = build_attention_mask(cfg.context_length).to(x.dtype)
+    for i in range(cfg.transformer_layers):
+        x = residual_block(x, p, f"transformer.resblocks.{i}.", cfg.transformer_heads, mask, bf16)
+    x = x[torch.arange(x.shape[0]), eot_index(text)]
+    x = layer_norm(x, p["ln_final.weight"], p["ln_final.bias"])
+    return _r(x, bf16) @ _r(p["text_projection"], bf16)
+
+
+def logits_from_features(image_features, text_features, logit_scale, overbatch: bool = True):
+    """Feature normalisation + logits (model_clip.py:496-521): no eps in the
+    norm, ``exp(logit_scale)`` unclamped, logits_per_text always over batch,
+    logits_per_image over batch (mm) or per instance (bmm)."""
+    i = image_features / image_features.norm(dim=-1, keepdim=True)
+    t = text_features / text_features.norm(dim=-1, keepdim=True)
+    s = logit_scale.exp()
+    logits_per_text = s * t @ i.t()
+    if overbatch:
+        logits_per_image = s * i @ t.t()
+    else:
+        B, E = i.shape
+        logits_per_image = s * torch.bmm(i.unsqueeze(1), t.view(B, -1, E).transpose(-2, -1))
+        logits_per_image = logits_per_image.squeeze(1)
+    return logits_per_image, logits_per_text
+
+
+def clip_forward(p, cfg: ClipConfig, image, text, overbatch: bool = True, bf16: bool = False):
+    """``CLIP.forward`` without ``train_arg`` (model_clip.py:419-423, :491-528)."""
+    fi = encode_image(p, cfg, image, bf16=bf16)
+    ft = encode_text(p, cfg, text, bf16=bf16)
+    return logits_from_features(fi, ft, p["logit_scale"], overbatch)
+
+
+def criterion_contrastive(logits_per_image, logits_per_text, labels_per_image=None,
+                          labels_per_text=None, index_pos=None, kind: str = "ce"):
+    """``CriterionContrastive.forward`` (model_clip.py:633-662).  Image side:
+    CE / BCE-with-logits / KLDiv (default 'mean' reduction, :623-629); text
+    side: positive rows selected by ``index_pos`` then CE (:655-659)."""
+    n = logits_per_image.shape[0]
+    if labels_per_image is None:
+        labels_per_image = torch.arange(n)
+    if labels_per_text is None:
+        labels_per_text = torch.arange(n)
+    if kind == "ce":
+        loss_i = F.cross_entropy(logits_per_image, labels_per_image)
+    elif kind == "bce":
+        loss_i = F.binary_cross_entropy_with_logits(logits_per_image, labels_per_image)
+    elif kind == "kl":
+        loss_i = F.kl_div(logits_per_image, labels_per_image, reduction="mean")
+    else:
+        raise RuntimeError("Invalid constrastive_loss '{}'. ".format(kind))
+    lt = logits_per_text.index_select(0, index_pos)
+    yt = labels_per_text.index_select(0, index_pos)
+    loss_t = F.cross_entropy(lt, yt)
+    return {"loss_i": loss_i, "loss_t": loss_t}
+
+
+# --------------------------------------------------------------------------- label layout
+
+def build_labels(batch: int, num_pos: int = 1, num_neg: int = 0, overbatch: bool = True,
+                 rank: int = 0):
+    """Label/index block of ``VOADescriptionDataset.collate_fn``
+    (dataset_voa.py:615-625, :652-663) and of the caption-only
+    ``VOADataset.collate_fn`` (:148-158, the num_neg=0, num_pos=1 case).
+    ``rank`` offsets the targets for the all-gathered global batch;
+    rank=0 is the reference's single-process layout."""
+    K = num_pos + num_neg
+    if num_pos != 1:
+        raise RuntimeError("Only constrative_loss=CrossEntropyLoss with description_num_pos == 1 is laid out here")
+    base = rank * batch
+    if overbatch:
+        labels_per_image = (torch.arange(batch) + base) * K
+    else:
+        labels_per_image = torch.zeros(batch, dtype=torch.long)
+    labels_per_text = (torch.arange(batch) + base).unsqueeze(1).expand(batch, K).flatten()
+    mask = torch.tensor([[1] * num_pos + [0] * num_neg for _ in range(batch)], dtype=torch.long).flatten()
+    index_pos = torch.nonzero(mask).flatten()
+    return labels_per_image, labels_per_text, index_pos
+
+
+# --------------------------------------------------------------------------- optimal transport
+
+def cost_matrix_cosine(x, y, eps: float = 1e-5):
+    """model_ot.py:8-18."""
+    xn = F.normalize(x, p=2, dim=-1, eps=eps)
+    yn = F.normalize(y, p=2, dim=-1, eps=eps)
+    return 1 - xn.matmul(yn.transpose(1, 2))
+
+
+@torch.no_grad()
+def ipot(C, x_len, x_pad, y_len, y_pad, joint_pad, beta: float, iteration: int, k: int):
+    """model_ot.py:32-63, statement for statement (the arithmetic order of the
+    delta/sigma updates is what the goldens pin, including the all-pad case)."""
+    b, m, n = C.shape
+    sigma = torch.ones(b, m, dtype=C.dtype) / x_len.unsqueeze(1)
+    T = torch.ones(b, n, m, dtype=C.dtype)
+    A = torch.exp(-C.transpose(1, 2) / beta)
+    sigma = sigma.masked_fill(x_pad, 0)
+    jp = joint_pad.transpose(1, 2)
+    T = T.masked_fill(jp, 0)
+    A = A.masked_fill(jp, 0)
+    xl = x_len.unsqueeze(1).unsqueeze(2)
+    yl = y_len.unsqueeze(1).unsqueeze(2)
+    x_mask = (x_pad.to(C.dtype) * 1e4).unsqueeze(1)
+    y_mask = (y_pad.to(C.dtype) * 1e4).unsqueeze(1)
+    delta = None
+    for _ in range(iteration):
+        Q = A * T
+        sigma = sigma.view(b, m, 1)
+        for _ in range(k):
+            delta = 1 / (yl * Q.matmul(sigma).view(b, 1, n) + y_mask)
+            sigma = 1 / (xl * delta.matmul(Q) + x_mask)
+        T = delta.view(b, n, 1) * Q * sigma
+    return T.masked_fill(jp, 0)
+
+
+def optimal_transport_dist(txt_emb, img_emb, txt_pad, img_pad, beta=0.5, iteration=50, k=1):
+    """model_ot.py:66-83: cosine cost, pads zeroed, IPOT plan on the detached
+    cost, distance = trace(C @ T) with T detached."""
+    cost = cost_matrix_cosine(txt_emb, img_emb)
+    joint_pad = txt_pad.unsqueeze(-1) | img_pad.unsqueeze(-2)
+    cost = cost.masked_fill(joint_pad, 0)
+    txt_len = (txt_pad.size(1) - txt_pad.sum(dim=1)).to(cost.dtype)
+    img_len = (img_pad.size(1) - img_pad.sum(dim=1)).to(cost.dtype)
+    T = ipot(cost.detach(), txt_len, txt_pad, img_len, img_pad, joint_pad, beta, iteration, k)
+    prod = cost.matmul(T.detach())                       # [B,M,M]
+    return torch.diagonal(prod, dim1=-2, dim2=-1).sum(-1)   # trace, model_ot.py:21-29
+
+
+def criterion_alignment(entitytxt_vec, object_vec, entitytxt_num, object_num):
+    """``CriterionAlignment.forward`` (model_clip.py:679-715): drop object slot 0
+    (the whole image), pad = (mask == 0), fp32 OT distance, sum * 0.01."""
+    img = object_vec[:, 1:]
+    txt_pad = entitytxt_num == 0
+    img_pad = object_num[:, 1:] == 0
+    d = optimal_transport_dist(entitytxt_vec.float(), img.float(), txt_pad, img_pad)
+    return {"loss_ot": d.sum() * 0.01}
+
+
+def sim_entity(p, cfg: ClipConfig, img_obj, txt_ent, bf16: bool = False):
+    """``CLIP.sim_entity`` (model_clip.py:531-552): un-normalised features."""
+    B, O = img_obj.shape[:2]
+    M = txt_ent.shape[1]
+    fi = encode_image(p, cfg, img_obj.reshape(B * O, *img_obj.shape[2:]), bf16=bf16).view(B, O, -1)
+    ft = encode_text(p, cfg, txt_ent.reshape(B * M, -1), bf16=bf16).view(B, M, -1)
+    return fi, ft
+
+
+# --------------------------------------------------------------------------- region / argument branch
+
+def patch_from_norm_bbox(bbox_norm, patch_size: int = 7):
+    """utils_image.py:28-32: floor of the mins, ceil of the maxes, times patch_size."""
+    x0, y0, x1, y1 = bbox_norm
+    return (math.floor(x0 * patch_size), math.floor(y0 * patch_size),
+            math.ceil(x1 * patch_size), math.ceil(y1 * patch_size))
+
+
+def region_losses(p, cfg: ClipConfig, grid_features, bboxs, bbox_desc_vec, bbox_label_vec=None,
+                  train_arg: str = "desc", bf16: bool = False):
+    """The ``train_arg`` branch of ``CLIP.forward`` (model_clip.py:430-488) with
+    ``loss_func = nn.CrossEntropyLoss()`` injected (the reference leaves it
+    undefined).  Quirks kept: the first grid axis is indexed by
+    the bbox x range (:439); an image is skipped when it has no usable box or
+    when its LAST box is None (:450-455)."""
+    loss_per_bbox = torch.zeros(())
+    loss_per_arg = torch.zeros(())
+    s = p["logit_scale"].exp()
+    for i, boxes in enumerate(bboxs):
+        feats, descs, labs = [], [], []
+        last = None
+        for j, bbox in enumerate(boxes):
+            last = bbox
+            if bbox is None:
+                continue
+            x0, y0, x1, y1 = patch_from_norm_bbox(bbox, cfg.grid)
+            region = grid_features[i, x0:x1, y0:y1, :].reshape(-1, grid_features.shape[-1])
+            feats.append(region.mean(dim=0))
+            descs.append(bbox_desc_vec[i][j])
+            if train_arg.startswith("desc_type"):
+                labs.append(bbox_label_vec[i][j])
+        if not descs or last is None:
+            continue
+        r = torch.stack(feats)
+        r = r / r.norm(dim=-1, keepdim=True)
+        d = encode_text(p, cfg, torch.stack(descs), bf16=bf16)
+        d = d / d.norm(dim=-1, keepdim=True)
+        y = torch.arange(r.shape[0])
+        loss_per_bbox = loss_per_bbox + F.cross_entropy(s * r @ d.t(), y)
+        loss_per_arg = loss_per_arg + F.cross_entropy(s * d @ r.t(), y)
+        if train_arg.startswith("desc_type"):
+            l = encode_text(p, cfg, torch.stack(labs), bf16=bf16)
+            l = l / l.norm(dim=-1, keepdim=True)
+            loss_per_bbox = loss_per_bbox + F.cross_entropy(s * r @ l.t(), y)
+            loss_per_arg = loss_per_arg + F.cross_entropy(s * l @ r.t(), y)
+            if train_arg.startswith("desc_type_text"):
+                loss_per_arg = loss_per_arg + F.cross_entropy(s * d @ l.t(), y)
+    return loss_per_bbox, loss_per_arg
+
+
+def clip_forward_train_arg(p, cfg, image, text, train_arg, bboxs, bbox_desc_vec, bbox_label_vec=None,
+                           overbatch=True, bf16=False):
+    """``CLIP.forward`` with ``train_arg`` (model_clip.py:423-426, :430-528)."""
+    f = encode_image(p, cfg, image, use_grid=True, bf16=bf16)
+    B = f.shape[0]
+    grid = f[:, 1:, :].reshape(B, cfg.grid, cfg.grid, -1)
+    fi = f[:, 0, :]
+    lb, la = region_losses(p, cfg, grid, bboxs, bbox_desc_vec, bbox_label_vec, train_arg, bf16)
+    ft = encode_text(p, cfg, text, bf16=bf16)
+    li, lt = logits_from_features(fi, ft, p["logit_scale"], overbatch)
+    return li, lt, lb, la
+
+
+# --------------------------------------------------------------------------- training step
+
+def loss_and_grads(p, cfg, image, text, labels_per_image, labels_per_text, index_pos,
+                   overbatch=True, kind="ce", bf16=False):
+    """Forward + loss SUM (engine.py:48-67) + backward (engine.py:88).
+    Returns (loss_dict, grads keyed like ``p``)."""
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    li, lt = clip_forward(q, cfg, image, text, overbatch, bf16)
+    ld = criterion_contrastive(li, lt, labels_per_image, labels_per_text, index_pos, kind)
+    total = sum(ld.values())
+    total.backward()
+    return {k: v.detach() for k, v in ld.items()}, {k: v.grad for k, v in q.items()}, (li.detach(), lt.detach())
+
+
+def clip_grad_norm(grads: Dict[str, torch.Tensor], max_norm: float = 1.0):
+    """``torch.nn.utils.clip_grad_norm_(params, 1)`` (engine.py:89): total L2
+    norm; coefficient ``max_norm / (norm + 1e-6)`` clamped to 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values() if g is not None)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, {k: (g * coef if g is not None else None) for k, g in grads.items()}
+
+
+def adam_step(p, grads, state, lr: float, weight_decay: float = 0.0,
+              betas=(0.9, 0.999), eps: float = 1e-8):
+    """``torch.optim.Adam`` with L2 weight decay (engine.py:141-146; not AdamW)."""
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    b1, b2 = betas
+    out = {}
+    for k, w in p.items():
+        g = grads[k]
+        if g is None:
+            out[k] = w
+            continue
+        if weight_decay != 0:
+            g = g + weight_decay * w
+        m = state.setdefault("m", {}).get(k, torch.zeros_like(w))
+        v = state.setdefault("v", {}).get(k, torch.zeros_like(w))
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        state["m"][k], state["v"][k] = m, v
+        mhat = m / (1 - b1 ** t)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** t)) + eps
+        out[k] = w - lr * mhat / denom
+    return out
+
+
+def train_step(p, cfg, state, image, text, labels_per_image, labels_per_text, index_pos,
+               lr=1e-6, weight_decay=0.0, overbatch=True, bf16=False):
+    """One iteration of ``train_one_epoch`` (engine.py:48-95) for the InfoNCE-only
+    configuration: forward, loss sum, backward, clip_grad_norm_(.,1), Adam."""
+    ld, grads, _ = loss_and_grads(p, cfg, image, text, labels_per_image, labels_per_text,
+                                  index_pos, overbatch, "ce", bf16)
+    total, grads = clip_grad_norm(grads, 1.0)
+    return adam_step(p, grads, state, lr, weight_decay), ld, total

@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Capture golden vectors by IMPORTING THE REFERENCE in the build container.
+
+Run (build container only; ``/root/reference`` does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What it does: puts ``/root/reference/src/clip-event`` on ``sys.path`` (nothing
+is copied; bytecode writing is disabled), injects two stub modules that exist
+only inside this process -- ``ftfy`` (``fix_text`` = identity, exact for the
+ASCII captions used here) and ``torchvision.transforms`` (five names that only
+``clip._transform`` touches) -- then drives the reference's own ``CLIP``,
+``CriterionContrastive``, ``CriterionAlignment``, ``model_ot``, ``clip.tokenize``
+and ``patch_from_norm_bbox`` on seeded inputs and writes inputs' seeds and the
+reference's outputs to ``tests/golden/*.npz`` / ``*.json``.
+
+Weights are this project's own seeded draw (``oracle.clip_oracle.init_params``)
+loaded into the reference with ``load_state_dict(strict=True)``; inputs come
+from ``clip_event_amd.synthetic``.  Both regenerate bit-identically on any box,
+so the fixtures hold only seeds and the reference's outputs.  For big tensors
+(gradients) a summary is stored: L2 norm, sum, and 32 evenly spaced samples.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src/clip-event"
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+# --- in-process stubs for modules absent from the image (not reference code) ---
+_ftfy = types.ModuleType("ftfy")
+_ftfy.fix_text = lambda s: s
+sys.modules["ftfy"] = _ftfy
+_tv = types.ModuleType("torchvision")
+_tvt = types.ModuleType("torchvision.transforms")
+for _n in ("Compose", "Resize", "CenterCrop", "ToTensor", "Normalize"):
+    setattr(_tvt, _n, lambda *a, **k: None)
+_tv.transforms = _tvt
+sys.modules["torchvision"] = _tv
+sys.modules["torchvision.transforms"] = _tvt
+
+import model_clip as ref_model          # noqa: E402  (the reference)
+import model_ot as ref_ot               # noqa: E402
+import utils_image as ref_img           # noqa: E402
+import clip as ref_clip                 # noqa: E402
+
+from oracle import clip_oracle as O     # noqa: E402
+from clip_event_amd import synthetic as S  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(999)
+
+TINY = O.ClipConfig(embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128,
+                    vision_patch_size=32, context_length=20, vocab_size=512,
+                    transformer_width=128, transformer_heads=2, transformer_layers=2)
+
+
+def summary(t: torch.Tensor, n: int = 32):
+    f = t.detach().double().flatten()
+    n = min(n, f.numel())
+    idx = (torch.arange(n, dtype=torch.int64) * (f.numel() - 1)) // max(n - 1, 1)
+    return {"norm": float(f.norm()), "sum": float(f.sum()), "idx": idx.tolist(),
+            "val": [float(x) for x in f[idx]]}
+
+
+def build_ref(cfg: O.ClipConfig, seed: int):
+    m = ref_model.CLIP(cfg.embed_dim, cfg.image_resolution, cfg.vision_layers, cfg.vision_width,
+                       cfg.vision_patch_size, cfg.context_length, cfg.vocab_size,
+                       cfg.transformer_width, cfg.transformer_heads, cfg.transformer_layers)
+    sd = O.init_params(cfg, seed)
+    assert list(m.state_dict().keys()) == list(sd.keys()), "state-dict key order drifted"
+    m.load_state_dict(sd, strict=True)
+    m.loss_func = torch.nn.CrossEntropyLoss()   # undefined in the reference
+    return m, sd
+
+
+def grads_of(m):
+    return {k: summary(p.grad) for k, p in m.named_parameters() if p.grad is not None}
+
+
+def np_save(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name), **{k: np.asarray(v) for k, v in arrs.items()})
+
+
+out = {}
+
+# ---------------------------------------------------------------- G1: tiny model, hard negatives
+def g_tiny():
+    cfg, seed = TINY, 11
+    m, sd = build_ref(cfg, seed)
+    B, K = 4, 3
+    img = S.synthetic_images(B, cfg.image_resolution, seed=21)
+    txt = S.synthetic_tokens(B * K, cfg.context_length, cfg.vocab_size, seed=22, min_len=2)
+    res = {"cfg": cfg.__dict__, "param_seed": seed, "B": B, "K": K, "img_seed": 21, "txt_seed": 22,
+           "txt_min_len": 2, "param_norm": summary(torch.cat([v.flatten() for v in sd.values()]))}
+    arrs = {}
+    for overbatch in (True, False):
+        m.set_hyps(constrastive_overbatch=overbatch)
+        m.zero_grad()
+        li, lt = m(img, txt)
+        crit = ref_model.CriterionContrastive("ce")
+        yi, yt, ip = O.build_labels(B, 1, K - 1, overbatch)
+        ld = crit(li, lt, yi, yt, index_pos=ip, constrastive_overbatch=overbatch)
+        (ld["loss_i"] + ld["loss_t"]).backward()
+        tag = "over" if overbatch else "inst"
+        arrs[f"{tag}_logits_per_image"] = li.detach().numpy()
+        arrs[f"{tag}_logits_per_text"] = lt.detach().numpy()
+        res[tag] = {"loss_i": float(ld["loss_i"]), "loss_t": float(ld["loss_t"]), "grads": grads_of(m)}
+    with torch.no_grad():
+        arrs["image_features"] = m.encode_image(img).numpy()
+        arrs["image_grid_features"] = m.encode_image(img, use_grid=True).numpy()
+        arrs["text_features"] = m.encode_text(txt).numpy()
+    # bce / kl image-side kinds on the per-instance logits
+    m.set_hyps(constrastive_overbatch=False)
+    with torch.no_grad():
+        li, lt = m(img, txt)
+        _, yt, ip = O.build_labels(B, 1, K - 1, False)
+        yb = torch.tensor([[1.] + [0.] * (K - 1)] * B)
+        for kind in ("bce", "kl"):
+            ld = ref_model.CriterionContrastive(kind)(li, lt, yb, yt, index_pos=ip, constrastive_overbatch=False)
+            res[kind] = {"loss_i": float(ld["loss_i"]), "loss_t": float(ld["loss_t"])}
+    np_save("tiny_forward.npz", **arrs)
+    return res
+
+
+# ---------------------------------------------------------------- G2: one Adam train step (tiny)
+def g_tiny_step():
+    cfg, seed = TINY, 11
+    m, sd = build_ref(cfg, seed)
+    B = 4
+    img = S.synthetic_images(B, cfg.image_resolution, seed=31)
+    txt = S.synthetic_tokens(B, cfg.context_length, cfg.vocab_size, seed=32, min_len=2)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)
+    crit = ref_model.CriterionContrastive("ce")
+    yi, yt, ip = O.build_labels(B, 1, 0, True)
+    res = {"lr": 1e-3, "weight_decay": 0.01, "steps": []}
+    for _ in range(2):
+        li, lt = m(img, txt)
+        ld = crit(li, lt, yi, yt, index_pos=ip, constrastive_overbatch=True)
+        losses = sum(ld.values())                      # engine.py:67
+        opt.zero_grad()
+        losses.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1)   # engine.py:89
+        opt.step()
+        res["steps"].append({"loss_i": float(ld["loss_i"]), "loss_t": float(ld["loss_t"]),
+                             "grad_norm": float(gn),
+                             "params_after": {k: summary(v) for k, v in m.state_dict().items()}})
+    return res
+
+
+# ---------------------------------------------------------------- G3: ViT-B/32, B=8, caption-only (config c1)
+def g_vitb32():
+    cfg, seed = O.VIT_B32, 0
+    m, sd = build_ref(cfg, seed)
+    B = 8
+    img = S.synthetic_images(B, 224, seed=999)
+    txt = ref_clip.tokenize(list(S.ASCII_CAPTIONS))
+    li, lt = m(img, txt)
+    crit = ref_model.CriterionContrastive("ce")
+    y = torch.arange(B)
+    ld = crit(li, lt, y, y, index_pos=y, constrastive_overbatch=True)
+    sum(ld.values()).backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    with torch.no_grad():
+        fi = m.encode_image(img).numpy()
+        ft = m.encode_text(txt).numpy()
+    np_save("vitb32_b8.npz", logits_per_image=li.detach().numpy(), logits_per_text=lt.detach().numpy(),
+            image_features=fi, text_features=ft, tokens=txt.numpy())
+    return {"param_seed": seed, "img_seed": 999, "loss_i": float(ld["loss_i"]), "loss_t": float(ld["loss_t"]),
+            "grad_norm": float(gn), "grads": grads_of(m),
+            "param_norm": summary(torch.cat([v.flatten() for v in sd.values()]))}
+
+
+# ---------------------------------------------------------------- G4: tokenizer
+TOKENIZER_CASES = list(S.ASCII_CAPTIONS) + [
+    "",
+    "a",
+    "Hello, World!",
+    "it's the president's 2nd visit; they've said they'll go, won't they?",
+    "U.S. troops in Iraq -- 1,500 of them (approx.) -- left on 12/31/2011",
+    "   leading and trailing   whitespace\tand\nnewlines  ",
+    "AT&amp;T &lt;tag&gt; &quot;quoted&quot; &amp;amp; twice",
+    "A man (left) hands a ballot to a woman (right) #election @city 100% $5.00",
+    "supercalifragilisticexpialidocious antidisestablishmentarianism",
+    "the quick brown fox jumps over the lazy dog " * 12,
+    "<|startoftext|> nested specials <|endoftext|> inside",
+    "x" * 300,
+]
+
+
+def g_tokenizer():
+    ids = ref_clip.tokenize(TOKENIZER_CASES)
+    ids20 = ref_clip.tokenize(TOKENIZER_CASES, context_length=20)
+    np_save("tokenizer.npz", ids77=ids.numpy(), ids20=ids20.numpy())
+    return {"cases": TOKENIZER_CASES, "argmax77": ids.argmax(-1).tolist(),
+            "vocab_size": len(ref_clip._tokenizer.encoder),
+            "sot": ref_clip._tokenizer.encoder["<|startoftext|>"],
+            "eot": ref_clip._tokenizer.encoder["<|endoftext|>"],
+            "decode0": ref_clip._tokenizer.decode(ids[1][1:int(ids[1].argmax())].tolist())}
+
+
+# ---------------------------------------------------------------- G5: optimal transport
+def g_ot():
+    rng = np.random.default_rng(77)
+    B, M, O_, D = 6, 5, 7, 32
+    txt = torch.from_numpy(rng.standard_normal((B, M, D), dtype=np.float32)).requires_grad_(True)
+    obj = torch.from_numpy(rng.standard_normal((B, O_, D), dtype=np.float32)).requires_grad_(True)
+    txt_num = torch.from_numpy((rng.random((B, M)) < 0.7).astype(np.int64))
+    obj_num = torch.from_numpy((rng.random((B, O_)) < 0.7).astype(np.int64))
+    txt_num[0] = 1; obj_num[0] = 1            # nothing padded
+    txt_num[1] = 0                            # all text rows padded (x_len = 0)
+    obj_num[2, 1:] = 0                        # all image rows padded (y_len = 0)
+    txt_num[3, :] = 0; txt_num[3, 0] = 1      # single entity
+    ld = ref_model.CriterionAlignment()(txt, obj, txt_num, obj_num)
+    finite = bool(torch.isfinite(ld["loss_ot"]))
+    gt = go = None
+    if finite:
+        ld["loss_ot"].backward()
+        gt, go = txt.grad.numpy(), obj.grad.numpy()
+    # raw pieces
+    with torch.no_grad():
+        tp = txt_num == 0
+        ip = obj_num[:, 1:] == 0
+        dist = ref_ot.optimal_transport_dist(txt.detach(), obj.detach()[:, 1:], tp, ip)
+        cost = ref_ot.cost_matrix_cosine(txt.detach(), obj.detach()[:, 1:])
+        jp = tp.unsqueeze(-1) | ip.unsqueeze(-2)
+        cost.masked_fill_(jp, 0)
+        tl = (tp.size(1) - tp.sum(1)).float()
+        il = (ip.size(1) - ip.sum(1)).float()
+        T = ref_ot.ipot(cost, tl, tp, il, ip, jp, 0.5, 50, 1)
+    arrs = dict(txt=txt.detach().numpy(), obj=obj.detach().numpy(), txt_num=txt_num.numpy(),
+                obj_num=obj_num.numpy(), dist=dist.numpy(), cost=cost.numpy(), T=T.numpy())
+    if finite:
+        arrs.update(grad_txt=gt, grad_obj=go)
+    # a second, larger, fully finite batch (no degenerate rows) for gradient parity
+    B2, M2, O2, D2 = 5, 11, 8, 64
+    txt2 = torch.from_numpy(rng.standard_normal((B2, M2, D2), dtype=np.float32)).requires_grad_(True)
+    obj2 = torch.from_numpy(rng.standard_normal((B2, O2, D2), dtype=np.float32)).requires_grad_(True)
+    tn2 = torch.from_numpy((rng.random((B2, M2)) < 0.6).astype(np.int64)); tn2[:, 0] = 1
+    on2 = torch.from_numpy((rng.random((B2, O2)) < 0.6).astype(np.int64)); on2[:, :2] = 1
+    l2 = ref_model.CriterionAlignment()(txt2, obj2, tn2, on2)["loss_ot"]
+    l2.backward()
+    arrs.update(txt2=txt2.detach().numpy(), obj2=obj2.detach().numpy(), txt_num2=tn2.numpy(), obj_num2=on2.numpy(),
+                grad_txt2=txt2.grad.numpy(), grad_obj2=obj2.grad.numpy())
+    np_save("ot.npz", **arrs)
+    return {"loss_ot": float(ld["loss_ot"]), "finite": finite, "loss_ot2": float(l2)}
+
+
+# ---------------------------------------------------------------- G6: region / argument branch (tiny)
+def g_region():
+    cfg, seed = TINY, 11
+    m, sd = build_ref(cfg, seed)
+    B = 5
+    img = S.synthetic_images(B, cfg.image_resolution, seed=41)
+    txt = S.synthetic_tokens(B, cfg.context_length, cfg.vocab_size, seed=42, min_len=2)
+    bboxs = S.synthetic_bboxes(B, seed=43, max_roles=3)
+    bboxs[1] = [None]                      # image with no usable box
+    bboxs[2] = [(0.1, 0.2, 0.9, 0.8), None]  # last box None => image skipped (quirk)
+    bboxs[3] = [None, (0.0, 0.0, 1.0, 1.0), (0.3, 0.3, 0.6, 0.7)]
+    desc = [S.synthetic_tokens(len(b), cfg.context_length, cfg.vocab_size, seed=50 + i, min_len=2) for i, b in enumerate(bboxs)]
+    lab = [S.synthetic_tokens(len(b), cfg.context_length, cfg.vocab_size, seed=60 + i, min_len=2) for i, b in enumerate(bboxs)]
+    res = {"bboxs": bboxs, "patch_idx": [[None if b is None else list(ref_img.patch_from_norm_bbox(b, cfg.grid)) for b in bb] for bb in bboxs]}
+    for mode in ("desc", "desc_type", "desc_type_text"):
+        m.zero_grad()
+        li, lt, lb, la = m(img, txt, train_arg=mode, bboxs=bboxs, bbox_desc_vec=desc, bbox_label_vec=lab)
+        (lb + la).backward()
+        res[mode] = {"loss_per_bbox": float(lb), "loss_per_arg": float(la), "grads": grads_of(m),
+                     "logits_per_image": li.detach().numpy().tolist()}
+    # bbox index goldens on the 7x7 grid of ViT-B/32
+    rng = np.random.default_rng(5)
+    cases = [(0.1, 0.1, 0.6, 0.7), (0.0, 0.0, 1.0, 1.0), (0.5, 0.5, 0.5, 0.5), (1 / 7, 2 / 7, 3 / 7, 4 / 7)]
+    for _ in range(40):
+        xs = np.sort(rng.random(2)); ys = np.sort(rng.random(2))
+        cases.append((float(xs[0]), float(ys[0]), float(xs[1]), float(ys[1])))
+    res["bbox7"] = [{"bbox": list(c), "idx": list(ref_img.patch_from_norm_bbox(c, 7))} for c in cases]
+    return res
+
+
+# ---------------------------------------------------------------- G7: sim_entity + alignment through the towers (tiny)
+def g_entity():
+    cfg, seed = TINY, 11
+    m, sd = build_ref(cfg, seed)
+    B, O_, M = 3, 4, 5
+    rng = np.random.default_rng(88)
+    obj = torch.from_numpy(rng.standard_normal((B, O_, 3, cfg.image_resolution, cfg.image_resolution), dtype=np.float32))
+    ent = S.synthetic_tokens(B * M, cfg.context_length, cfg.vocab_size, seed=89, min_len=2).view(B, M, -1)
+    on = torch.from_numpy((rng.random((B, O_)) < 0.7).astype(np.int64)); on[:, :2] = 1
+    en = torch.from_numpy((rng.random((B, M)) < 0.7).astype(np.int64)); en[:, 0] = 1
+    fi, ft = m.sim_entity(obj, ent)
+    ld = ref_model.CriterionAlignment()(ft, fi, en, on)
+    ld["loss_ot"].backward()
+    np_save("entity.npz", obj_num=on.numpy(), ent_num=en.numpy(), image_features=fi.detach().numpy(),
+            text_features=ft.detach().numpy())
+    return {"loss_ot": float(ld["loss_ot"]), "grads": grads_of(m)}
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    jobs = {"tiny": g_tiny, "tiny_step": g_tiny_step, "vitb32": g_vitb32, "tokenizer": g_tokenizer,
+            "ot": g_ot, "region": g_region, "entity": g_entity}
+    path = os.path.join(HERE, "golden.json")
+    if os.path.exists(path):
+        out = json.load(open(path))
+    for k, fn in jobs.items():
+        if only and k not in only:
+            continue
+        print("capturing", k, flush=True)
+        out[k] = fn()
+    out["_meta"] = {"torch": torch.__version__, "numpy": np.__version__,
+                    "reference": "limanling/clip-event @ /root/reference (imported, CPU fp32)"}
+    json.dump(out, open(path, "w"), separators=(",", ":"))
+    print("wrote", path)

@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests."""
+import json
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN_DIR = os.path.join(HERE, "golden")
+
+
+def golden_json():
+    with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+        return json.load(f)
+
+
+def golden_npz(name):
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+def summary_of(t: torch.Tensor, idx):
+    f = t.detach().double().flatten().cpu()
+    return float(f.norm()), float(f.sum()), f[torch.tensor(idx, dtype=torch.long)].numpy()
+
+
+def check_summary(t: torch.Tensor, gold: dict, rtol: float, name: str = "", atol_frac: float = 1e-6):
+    """Compare a tensor against a golden {norm,sum,idx,val} summary.  The tolerance on the
+    sampled values is relative to the tensor's RMS magnitude (norm / sqrt(n))."""
+    norm, s, vals = summary_of(t, gold["idx"])
+    n = t.numel()
+    rms = gold["norm"] / max(n, 1) ** 0.5
+    assert abs(norm - gold["norm"]) <= rtol * gold["norm"] + 1e-12, f"{name}: norm {norm} vs {gold['norm']}"
+    err = np.abs(vals - np.asarray(gold["val"])).max()
+    assert err <= rtol * max(rms, 1e-30) * 10 + atol_frac * rms, f"{name}: sample err {err} (rms {rms})"
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
