@@ -1,0 +1,51 @@
+"""ctypes binding of libclip_event_hip.so (the C ABI in include/clip_event_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a call fails, this
+raises.  Tensors are passed as raw device pointers (`tensor.data_ptr()`), the stream as
+`torch.cuda.current_stream().cuda_stream`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclip_event_hip.so")
+_lib = None
+
+EPI_BF16, EPI_F32, EPI_BIAS_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_GELU, EPI_GELUGRAD_BF16 = range(7)
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load the shared library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                f"{LIB_PATH} not found: build it with `python -m clip_event_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ce_last_error.restype = c_char_p
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().ce_last_error().decode()}")
+
+
+def ptr(t) -> c_void_p:
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

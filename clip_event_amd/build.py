@@ -1,0 +1,65 @@
+"""Build libclip_event_hip.so in-tree with hipcc for gfx950 (no JIT cache, no torch extension).
+
+`python -m clip_event_amd.build` or `clip_event_amd.build.build()`.  The .so is git-ignored
+but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libclip_event_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value", f"--offload-arch={ARCH}"]
+HEADER = os.path.join(os.path.dirname(HERE), "include", "clip_event_hip.h")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [HEADER]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in sources() + _headers())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not force and not _stale():
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            continue
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,345 @@
+// Fused multi-head self-attention forward / backward for short sequences (gfx950, wave64).
+//
+// Replaces the attention core of nn.MultiheadAttention as called at model_clip.py:175,188
+// (need_weights=False; additive causal mask for the text tower, model_clip.py:377-384; no
+// padding mask) and its autograd: per (sample, head)  O = softmax(Q K^T / sqrt(64) + mask) V.
+// Sequences are 50 (ViT-B/32) or 77 (text) tokens, head_dim 64, so one workgroup owns one
+// (sample, head): K and V (and Q, dO in the backward) sit in LDS as [token][64] bf16 images
+// with a 160-byte row stride, which is bank-conflict free both for ds_read_b128 row fragments
+// and for ds_read_b64_tr_b16 transposed fragments.
+//
+// Forward, per wave and 16-query strip, all v_mfma_f32_16x16x32_bf16:
+//   S^T = K Q^T      (keys on accumulator rows, queries on lanes -> a query's scores live in
+//                     4 lanes x 4T registers; softmax row-reduce = in-lane + 2 shuffles)
+//   O^T = V^T P^T    (P^T is taken straight from the S^T accumulators as the B operand; the
+//                     permuted contraction order is matched by the transposed V reads)
+// Backward: phase 1 per query strip recomputes P from the saved log-sum-exp, forms
+//   dS = scale * P (dP - delta), writes P^T / dS^T (bf16) to LDS and computes dQ^T = K^T dS^T;
+// phase 2 per 16-key tile computes dV^T = dO^T P and dK^T = Q^T dS from the LDS images.
+#include "common.hpp"
+#include "../../include/clip_event_hip.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim (both towers, model_clip.py:307 / :600)
+constexpr int ROW = 160;        // LDS row stride in bytes: 128 + 32 pad
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    u32x4 v = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// cooperative copy of one [L][64] head slice (row stride ld elements) into an LDS image, rows
+// >= L zero-filled up to Lp
+__device__ __forceinline__ void stage_head(char* dst, const bf16_t* src, long ld, int L, int Lp, int tid, int nthr) {
+    for (int idx = tid; idx < Lp * 8; idx += nthr) {
+        const int r = idx >> 3, c = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < L) v = *reinterpret_cast<const u32x4*>(src + (long)r * ld + c * 8);
+        *reinterpret_cast<u32x4*>(dst + r * ROW + c * 16) = v;
+    }
+}
+
+template <int T>  // T = Lp / 16 key tiles (Lp = L rounded up to 32)
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
+                                                       long ldo, float* __restrict__ lse, int L, int H, int D,
+                                                       int causal, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = T * 16;
+    char* sK = smem;
+    char* sV = smem + Lp * ROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
+
+    stage_head(sK, base + D, ld, L, Lp, tid, blockDim.x);
+    stage_head(sV, base + 2 * D, ld, L, Lp, tid, blockDim.x);
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    const int nstrips = (L + 15) >> 4;
+    for (int strip = wave; strip < nstrips; strip += nw) {
+        const int i = strip * 16 + li;               // this lane's query
+        const int iq = min(i, L - 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+        f32x4 s[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+        }
+        // lane holds S^T[j = 16t + 4g + r][i]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + g * 4 + r;
+                const bool ok = (j < L) && (!causal || j <= i);
+                s[t][r] = ok ? s[t][r] * scale : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = __expf(s[t][r] - mx);
+                sum += s[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // O^T = V^T P^T : contraction element jj of lane-group g <-> key 32s + 16*(jj>>2) + 4g + (jj&3)
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < T / 2; ++sidx) {
+            bf16x8 pf = pack8(s[2 * sidx], s[2 * sidx + 1]);
+            const char* vrow = sV + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 vf = tr_pair(vrow + ct * 32, vrow + ct * 32 + 16 * ROW);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[ct], 0, 0, 0);
+            }
+        }
+        if (i < L) {
+            const float inv = 1.0f / sum;
+            bf16_t* orow = o + ((long)b * L + i) * ldo + h * HD + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                u32x2 pk = {pack_bf2(acc[ct][0] * inv, acc[ct][1] * inv), pack_bf2(acc[ct][2] * inv, acc[ct][3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + ct * 16) = pk;
+            }
+            if (g == 0) lse[((long)b * H + h) * L + i] = mx + __logf(sum);
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                       const bf16_t* __restrict__ o, long ldo,
+                                                       const bf16_t* __restrict__ dout, long lddo,
+                                                       const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                       long lddq, int L, int H, int D, int causal, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = T * 16;
+    constexpr int PROW = Lp * 2 + 32;            // stride of the P^T / dS^T images: = 32 (mod 64) bytes
+    char* sQ = smem;
+    char* sK = sQ + Lp * ROW;
+    char* sV = sK + Lp * ROW;
+    char* sDO = sV + Lp * ROW;
+    char* sP = sDO + Lp * ROW;
+    char* sDS = sP + Lp * PROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
+    const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
+    const bf16_t* ob = o + (long)b * L * ldo + h * HD;
+    bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
+
+    stage_head(sQ, base, ld, L, Lp, tid, blockDim.x);
+    stage_head(sK, base + D, ld, L, Lp, tid, blockDim.x);
+    stage_head(sV, base + 2 * D, ld, L, Lp, tid, blockDim.x);
+    stage_head(sDO, dob, lddo, L, Lp, tid, blockDim.x);
+    __syncthreads();
+
+    const int li = lane & 15, g = lane >> 4;
+    // ---------------- phase 1: per 16-query strip ----------------
+    for (int strip = wave; strip < T; strip += nw) {
+        const int i = strip * 16 + li;
+        const bool iok = i < L;
+        const int iq = min(i, L - 1);
+        // delta_i = sum_c dO[i][c] O[i][c]; each of the 4 lanes of a query takes 16 columns
+        float dl = 0.f;
+        {
+            const u32x4* pd = reinterpret_cast<const u32x4*>(dob + (long)iq * lddo + g * 16);
+            const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)iq * ldo + g * 16);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                u32x4 a = pd[v], c = po[v];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dl += bf_lo(a[e]) * bf_lo(c[e]) + bf_hi(a[e]) * bf_hi(c[e]);
+            }
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+        }
+        const float lsei = lse[((long)b * H + h) * L + iq];
+        bf16x8 qf[2], df[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(sQ + iq * ROW + (ks * 4 + g) * 16);
+            df[ks] = *reinterpret_cast<const bf16x8*>(sDO + iq * ROW + (ks * 4 + g) * 16);
+        }
+        f32x4 p[T], ds[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], p[t], 0, 0, 0);     // S^T
+                ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[ks], ds[t], 0, 0, 0);   // dP^T
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + g * 4 + r;
+                const bool ok = iok && (j < L) && (!causal || j <= i);
+                const float pv = ok ? __expf(p[t][r] * scale - lsei) : 0.f;
+                p[t][r] = pv;
+                ds[t][r] = pv * (ds[t][r] - dl) * scale;
+                // P^T / dS^T images [j][i] for phase 2
+                *reinterpret_cast<bf16_t*>(sP + j * PROW + i * 2) = f2bf(pv);
+                *reinterpret_cast<bf16_t*>(sDS + j * PROW + i * 2) = f2bf(ds[t][r]);
+            }
+        }
+        // dQ^T = K^T dS^T (dS^T straight from the accumulators, K^T by transposed reads)
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < T / 2; ++sidx) {
+            bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
+            const char* krow = sK + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 kf = tr_pair(krow + ct * 32, krow + ct * 32 + 16 * ROW);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, acc[ct], 0, 0, 0);
+            }
+        }
+        if (iok) {
+            bf16_t* qrow = dbase + (long)i * lddq + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                u32x2 pk = {pack_bf2(acc[ct][0], acc[ct][1]), pack_bf2(acc[ct][2], acc[ct][3])};
+                *reinterpret_cast<u32x2*>(qrow + ct * 16) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 2: per 16-key tile ----------------
+    const int nkt = (L + 15) >> 4;
+    for (int jt = wave; jt < nkt; jt += nw) {
+        const int j = jt * 16 + li;
+        f32x4 av[4], ak[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            av[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ak[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < T / 2; ++sidx) {
+            // B operands: P[i][j] / dS[i][j] as 8 consecutive i of row j of the transposed images
+            bf16x8 pf = *reinterpret_cast<const bf16x8*>(sP + j * PROW + (32 * sidx + 8 * g) * 2);
+            bf16x8 sf = *reinterpret_cast<const bf16x8*>(sDS + j * PROW + (32 * sidx + 8 * g) * 2);
+            // A operands: dO^T / Q^T rows c, contraction i = 32s + 8g + jj (natural order)
+            const int roff = (32 * sidx + 8 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 dof = tr_pair(sDO + roff + ct * 32, sDO + roff + ct * 32 + 4 * ROW);
+                bf16x8 qf = tr_pair(sQ + roff + ct * 32, sQ + roff + ct * 32 + 4 * ROW);
+                av[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, av[ct], 0, 0, 0);
+                ak[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[ct], 0, 0, 0);
+            }
+        }
+        if (j < L) {
+            bf16_t* krow = dbase + (long)j * lddq + D + 4 * g;
+            bf16_t* vrow = dbase + (long)j * lddq + 2 * D + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                u32x2 pk = {pack_bf2(ak[ct][0], ak[ct][1]), pack_bf2(ak[ct][2], ak[ct][3])};
+                u32x2 pv = {pack_bf2(av[ct][0], av[ct][1]), pack_bf2(av[ct][2], av[ct][3])};
+                *reinterpret_cast<u32x2*>(krow + ct * 16) = pk;
+                *reinterpret_cast<u32x2*>(vrow + ct * 16) = pv;
+            }
+        }
+    }
+}
+
+int tiles_for(int L) { return ((L + 31) / 32) * 2; }
+
+}  // namespace
+
+#define ATTN_DISPATCH(T, CALL)                 \
+    switch (T) {                               \
+        case 2: CALL(2); break;                \
+        case 4: CALL(4); break;                \
+        case 6: CALL(6); break;                \
+        case 8: CALL(8); break;                \
+        default: CE_CHECK_ARG(false, "attention: sequence length %d not supported (max 128)", L); \
+    }
+
+extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, int B, int L, int H,
+                                int causal, void* stream) {
+    CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_fwd: empty problem");
+    CE_CHECK_ARG(ld % 8 == 0 && ldo % 4 == 0, "ce_attention_fwd: ld must be a multiple of 8, ldo of 4");
+    const int D = H * HD;
+    const int T = tiles_for(L);
+    const int Lp = T * 16;
+    int nw = (L + 15) / 16;
+    if (nw > 8) nw = 8;
+    const size_t lds = 2 * (size_t)Lp * ROW;
+    const float scale = 0.125f;  // 1/sqrt(64)
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(TT)                                                                                              \
+    hipLaunchKernelGGL(attn_fwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, \
+                       lse, L, H, D, causal, scale)
+    ATTN_DISPATCH(T, CALL);
+#undef CALL
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
+                                const float* lse, void* dqkv, long lddq, int B, int L, int H, int causal,
+                                void* stream) {
+    CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_bwd: empty problem");
+    CE_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0, "ce_attention_bwd: bad leading dimension");
+    const int D = H * HD;
+    const int T = tiles_for(L);
+    const int Lp = T * 16;
+    int nw = T;
+    if (nw > 8) nw = 8;
+    const size_t lds = 4 * (size_t)Lp * ROW + 2 * (size_t)Lp * (Lp * 2 + 32);
+    const float scale = 0.125f;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(TT)                                                                                                   \
+    do {                                                                                                           \
+        static bool attr = false;                                                                                  \
+        if (!attr) {                                                                                               \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<TT>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL(attn_bwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld,        \
+                           (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, L, H, D, causal, \
+                           scale);                                                                                 \
+    } while (0)
+    ATTN_DISPATCH(T, CALL);
+#undef CALL
+    CE_LAUNCH_CHECK();
+    return 0;
+}

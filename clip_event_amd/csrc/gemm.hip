@@ -1,0 +1,447 @@
+// bf16 MFMA GEMMs for the CLIP-Event towers (gfx950 / CDNA4, wave64).
+//
+//   ce_gemm_nt : C[M,N]   = A[M,K] . B[N,K]^T  (+ fused epilogues)   forward + dgrad
+//   ce_gemm_tn : O[Nn,Kk] += P[M,Nn]^T . Q[M,Kk]   (fp32 atomics)     wgrad
+//
+// Replaces the nn.Linear / nn.MultiheadAttention in/out-projection / Conv2d(stride=kernel)
+// GEMMs of the reference (model_clip.py:175-180, :219, :230, :329) and their autograd.
+//
+// NT tile: 128x128x64, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16
+// tiles.  The weight rows feed the MFMA A operand and the activation rows the B operand,
+// so a lane's 4 accumulator registers are 4 consecutive output columns n of one output
+// row m (8-byte bf16 / 16-byte fp32 epilogue accesses).  Operands are staged global ->
+// VGPR -> LDS one K-tile ahead (double-buffered LDS, one barrier per K-tile) with the
+// 16-byte-chunk XOR swizzle chunk ^= row&7 that makes the ds_read_b128 fragment reads
+// bank-conflict free on 128-byte rows.
+//
+// TN tile: 128(n) x 128(k) outputs, contraction over 64-row m tiles, 4 waves (2x2), each
+// 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles.  Both operands are contraction-major in HBM,
+// so fragments come from ds_read_b64_tr_b16 (hardware transposed LDS read) on row-major
+// [m][128] LDS tiles padded to a 320-byte row stride (conflict-free for the 4-row x 64-byte
+// footprint of a half-wave).  Output columns sit on the lane (col = lane&31), so every
+// accumulator register is two 128-byte row segments: the full-rate shape for
+// global_atomic_add_f32.  The M range is split across workgroups to fill the chip.
+#include "common.hpp"
+#include "../../include/clip_event_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------
+constexpr int NT_BM = 128, NT_BN = 128, NT_BK = 64;
+constexpr int NT_STAGE_BYTES = (NT_BM + NT_BN) * NT_BK * 2;  // 32 KiB
+constexpr int NT_LDS_BYTES = 2 * NT_STAGE_BYTES;             // 64 KiB
+
+struct NTArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* B; long ldb;
+    int M, N, K;
+    const float* bias;
+    const float* resid; long ldr;
+    void* out; long ldo;
+    bf16_t* out2; long ldo2;
+    const bf16_t* aux; long ldaux;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
+    // range of tiles so neighbouring tiles (same A row panel) hit the same L2.  Bijective
+    // for any nwg.  Speed only, never correctness.
+    int xcd = bid & 7, local = bid >> 3;
+    int q = nwg >> 3, r = nwg & 7;
+    int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + local;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * NT_BM, n0 = tn * NT_BN;
+
+    const int rowsA = min(p.M - m0, NT_BM), rowsB = min(p.N - n0, NT_BN);
+    __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + (long)m0 * p.lda, (uint32_t)((long)rowsA * p.lda * 2));
+    __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + (long)n0 * p.ldb, (uint32_t)((long)rowsB * p.ldb * 2));
+
+    // staging map: 16-byte chunk q = tid + 256*i -> row = q>>3, chunk c = q&7
+    const int s_c = tid & 7;
+    const int s_row = tid >> 3;  // + 32*i
+    const uint32_t gA0 = (uint32_t)(s_row * p.lda * 2 + s_c * 16);
+    const uint32_t gB0 = (uint32_t)(s_row * p.ldb * 2 + s_c * 16);
+    const uint32_t gAstep = (uint32_t)(32 * p.lda * 2), gBstep = (uint32_t)(32 * p.ldb * 2);
+    const int lds_w = s_row * 128 + ((s_c ^ (s_row & 7)) << 4);  // + 4096*i (32 rows * 128 B), swizzle unchanged
+
+    u32x4 ra[4], rb[4];
+    auto issue_loads = [&](int kt) {
+        const uint32_t kb = (uint32_t)(kt * NT_BK * 2);
+        const bool kvalid = (kt * NT_BK + s_c * 8) < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            ra[i] = kvalid ? __builtin_amdgcn_raw_buffer_load_b128(rA, gA0 + i * gAstep + kb, 0, 0) : z;
+            rb[i] = kvalid ? __builtin_amdgcn_raw_buffer_load_b128(rB, gB0 + i * gBstep + kb, 0, 0) : z;
+        }
+    };
+    auto write_stage = [&](int stage) {
+        char* sa = smem + stage * NT_STAGE_BYTES;
+        char* sb = sa + NT_BM * NT_BK * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(sa + lds_w + i * 4096) = ra[i];
+            *reinterpret_cast<u32x4*>(sb + lds_w + i * 4096) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + NT_BK - 1) / NT_BK;
+    issue_loads(0);
+    write_stage(0);
+    __syncthreads();
+
+    // fragment read map: row = base + (lane&15), k-chunk = ks*4 + (lane>>4); swizzle = row&7 = lane&7
+    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
+    const int fa_base = (wm * 64 + f_row) * 128;
+    const int fb_base = NT_BM * NT_BK * 2 + (wn * 64 + f_row) * 128;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue_loads(kt + 1);
+        const char* st = smem + cur * NT_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + f_kc) ^ f_sw) << 4;
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + t * 2048 + coff);
+                wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) write_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m][n..n+3], m = lane&15 within the 16x16 tile ----
+    const int em = m0 + wm * 64 + (lane & 15);
+    const int en = n0 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = em + mt * 16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = en + nt * 16;
+            if (n >= p.N) continue;
+            f32x4 v = acc[mt][nt];
+            if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                          EPI == CE_EPI_BIAS_F32) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v += b;
+            }
+            if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
+                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+            } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
+            } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
+                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + n);
+                v += r;
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
+            } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
+                // out = pre-activation a (bf16, kept for the backward), out2 = QuickGELU(a) (bf16)
+                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+                u32x2 g = {pack_bf2(quick_gelu_f(v[0]), quick_gelu_f(v[1])),
+                           pack_bf2(quick_gelu_f(v[2]), quick_gelu_f(v[3]))};
+                *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = g;
+            } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+                // out = acc * QuickGELU'(a), a = saved bf16 pre-activation
+                u32x2 a = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
+                u32x2 o = {pack_bf2(v[0] * quick_gelu_grad_f(bf_lo(a[0])), v[1] * quick_gelu_grad_f(bf_hi(a[0]))),
+                           pack_bf2(v[2] * quick_gelu_grad_f(bf_lo(a[1])), v[3] * quick_gelu_grad_f(bf_hi(a[1])))};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN kernel (wgrad)
+// ------------------------------------------------------------------------------------------
+constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 64;
+constexpr int TN_ROW = 320;                              // bytes: 256 + 64 pad
+constexpr int TN_TILE_BYTES = TN_BM * TN_ROW;            // 20480
+constexpr int TN_STAGE_BYTES = 2 * TN_TILE_BYTES;        // 40960
+constexpr int TN_LDS_BYTES = 2 * TN_STAGE_BYTES;         // 81920
+
+struct TNArgs {
+    const bf16_t* P; long ldp;
+    const bf16_t* Q; long ldq;
+    float* out; long ldo;
+    int M, Nn, Kk;
+    int tiles_n, tiles_k, splits, m_per_split;  // m_per_split multiple of 64
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int byte_off) {
+    // two ds_read_b64_tr_b16: rows r..r+3 and r+4..r+7 of a [m][cols] image -> 8 contraction values
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + byte_off));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + byte_off + 4 * TN_ROW));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.splits;
+    bid /= p.splits;
+    const int tk = bid % p.tiles_k, tn = bid / p.tiles_k;
+    const int n0 = tn * TN_BN, k0 = tk * TN_BK;
+    const int ms = split * p.m_per_split;
+    const int me = min(p.M, ms + p.m_per_split);
+    if (ms >= me) return;  // uniform per block
+    const int rows = me - ms;
+
+    __amdgpu_buffer_rsrc_t rP = make_rsrc(p.P + (long)ms * p.ldp, (uint32_t)((long)rows * p.ldp * 2));
+    __amdgpu_buffer_rsrc_t rQ = make_rsrc(p.Q + (long)ms * p.ldq, (uint32_t)((long)rows * p.ldq * 2));
+
+    // staging: chunk q = tid + 256*i -> row = q>>4 (0..63), c = q&15 (8 columns each)
+    const int s_c = tid & 15, s_row = tid >> 4;  // + 16*i
+    const bool pvalid = (n0 + s_c * 8) < p.Nn, qvalid = (k0 + s_c * 8) < p.Kk;
+    const uint32_t gP0 = (uint32_t)(s_row * p.ldp * 2 + (n0 + s_c * 8) * 2);
+    const uint32_t gQ0 = (uint32_t)(s_row * p.ldq * 2 + (k0 + s_c * 8) * 2);
+    const uint32_t gPstep = (uint32_t)(16 * p.ldp * 2), gQstep = (uint32_t)(16 * p.ldq * 2);
+    const int lds_w = s_row * TN_ROW + s_c * 16;  // + i*16*TN_ROW
+
+    u32x4 rp[4], rq[4];
+    auto issue_loads = [&](int mt) {
+        const uint32_t mbP = (uint32_t)((long)mt * TN_BM * p.ldp * 2);
+        const uint32_t mbQ = (uint32_t)((long)mt * TN_BM * p.ldq * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            rp[i] = pvalid ? __builtin_amdgcn_raw_buffer_load_b128(rP, gP0 + i * gPstep + mbP, 0, 0) : z;
+            rq[i] = qvalid ? __builtin_amdgcn_raw_buffer_load_b128(rQ, gQ0 + i * gQstep + mbQ, 0, 0) : z;
+        }
+    };
+    auto write_stage = [&](int stage) {
+        char* sp = smem + stage * TN_STAGE_BYTES;
+        char* sq = sp + TN_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(sp + lds_w + i * 16 * TN_ROW) = rp[i];
+            *reinterpret_cast<u32x4*>(sq + lds_w + i * 16 * TN_ROW) = rq[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read map (32x32x16 operand): 16-lane group g = lane>>4 reads the 4-row block
+    // rows 8*(g>>1) + {0..3} (then +4), columns 16*(g&1) + {0..15}; lane 4q+p of the group
+    // supplies row q, columns 4p..4p+3 and receives column (lane&15).
+    const int g = lane >> 4, li = lane & 15;
+    const int t_off = (8 * (g >> 1) + (li >> 2)) * TN_ROW + (16 * (g & 1) + 4 * (li & 3)) * 2;
+    const int tp_base = t_off + (wn * 64) * 2;                    // in P tile
+    const int tq_base = TN_TILE_BYTES + t_off + (wk * 64) * 2;    // in Q tile
+
+    const int nmt = (rows + TN_BM - 1) / TN_BM;
+    issue_loads(0);
+    write_stage(0);
+    __syncthreads();
+    for (int mt = 0; mt < nmt; ++mt) {
+        const int cur = mt & 1;
+        if (mt + 1 < nmt) issue_loads(mt + 1);
+        const char* st = smem + cur * TN_STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // 16 contraction rows per step
+            bf16x8 pf[2], qf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pf[t] = tr_frag(st, tp_base + s * 16 * TN_ROW + t * 64);
+                qf[t] = tr_frag(st, tq_base + s * 16 * TN_ROW + t * 64);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
+        }
+        if (mt + 1 < nmt) write_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row n][col k]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int ek = k0 + wk * 64 + (lane & 31);
+    const int en = n0 + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k = ek + kt * 32;
+            if (k >= p.Kk) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+                if (n < p.Nn) atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// probes: raw fragment in / raw accumulator out, so the host can check the lane maps
+// ------------------------------------------------------------------------------------------
+__global__ void probe_mfma16_kernel(const bf16x8* a, const bf16x8* b, f32x4* out) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[threadIdx.x], b[threadIdx.x], c, 0, 0, 0);
+    out[threadIdx.x] = c;
+}
+__global__ void probe_mfma32_kernel(const bf16x8* a, const bf16x8* b, f32x16* out) {
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[threadIdx.x], b[threadIdx.x], c, 0, 0, 0);
+    out[threadIdx.x] = c;
+}
+__global__ void probe_tr16_kernel(const uint16_t* image, int n_elems, const int* byte_off, s16x4* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* l = reinterpret_cast<uint16_t*>(smem);
+    for (int i = threadIdx.x; i < n_elems; i += 64) l[i] = image[i];
+    __syncthreads();
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    out[threadIdx.x] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + byte_off[threadIdx.x]));
+}
+
+template <int EPI>
+int launch_nt(const NTArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ce_gemm_nt(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int epilogue,
+                          const float* bias, const float* resid, long ldr, void* out, long ldo, void* out2,
+                          long ldo2, const void* aux, long ldaux, void* stream) {
+    CE_CHECK_ARG(M > 0 && N > 0 && K > 0, "ce_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+    CE_CHECK_ARG(K % 8 == 0 && N % 4 == 0, "ce_gemm_nt: need K%%8==0 and N%%4==0 (K=%d N=%d)", K, N);
+    CE_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldo % 4 == 0, "ce_gemm_nt: lda/ldb must be multiples of 8, ldo of 4");
+    CE_CHECK_ARG(lda >= K && ldb >= K && ldo >= N, "ce_gemm_nt: leading dimension smaller than the row");
+    CE_CHECK_ARG(128L * lda * 2 < (1L << 32) && 128L * ldb * 2 < (1L << 32), "ce_gemm_nt: row panel exceeds 4 GiB");
+    NTArgs a;
+    a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb;
+    a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid; a.ldr = ldr;
+    a.out = out; a.ldo = ldo; a.out2 = (bf16_t*)out2; a.ldo2 = ldo2; a.aux = (const bf16_t*)aux; a.ldaux = ldaux;
+    a.tiles_m = ce_div_up(M, NT_BM); a.tiles_n = ce_div_up(N, NT_BN);
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case CE_EPI_BF16: return launch_nt<CE_EPI_BF16>(a, s);
+        case CE_EPI_F32: return launch_nt<CE_EPI_F32>(a, s);
+        case CE_EPI_BIAS_BF16:
+            CE_CHECK_ARG(bias, "ce_gemm_nt: bias epilogue without bias");
+            return launch_nt<CE_EPI_BIAS_BF16>(a, s);
+        case CE_EPI_BIAS_F32:
+            CE_CHECK_ARG(bias, "ce_gemm_nt: bias epilogue without bias");
+            return launch_nt<CE_EPI_BIAS_F32>(a, s);
+        case CE_EPI_BIAS_RESID_F32:
+            CE_CHECK_ARG(bias && resid && ldr >= N && ldr % 4 == 0, "ce_gemm_nt: residual epilogue needs bias+resid");
+            return launch_nt<CE_EPI_BIAS_RESID_F32>(a, s);
+        case CE_EPI_BIAS_GELU:
+            CE_CHECK_ARG(bias && out2 && ldo2 >= N && ldo2 % 4 == 0, "ce_gemm_nt: gelu epilogue needs bias+out2");
+            return launch_nt<CE_EPI_BIAS_GELU>(a, s);
+        case CE_EPI_GELUGRAD_BF16:
+            CE_CHECK_ARG(aux && ldaux >= N && ldaux % 4 == 0, "ce_gemm_nt: gelu-grad epilogue needs aux");
+            return launch_nt<CE_EPI_GELUGRAD_BF16>(a, s);
+        default: CE_CHECK_ARG(false, "ce_gemm_nt: unknown epilogue %d", epilogue);
+    }
+    return 0;
+}
+
+extern "C" int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out,
+                          long ldo, int splits, void* stream) {
+    CE_CHECK_ARG(M > 0 && Nn > 0 && Kk > 0, "ce_gemm_tn: empty problem");
+    CE_CHECK_ARG(Nn % 8 == 0 && Kk % 8 == 0 && ldp % 8 == 0 && ldq % 8 == 0, "ce_gemm_tn: Nn,Kk,ldp,ldq must be multiples of 8");
+    CE_CHECK_ARG(ldp >= Nn && ldq >= Kk && ldo >= Kk, "ce_gemm_tn: leading dimension smaller than the row");
+    TNArgs a;
+    a.P = (const bf16_t*)P; a.ldp = ldp; a.Q = (const bf16_t*)Q; a.ldq = ldq; a.out = out; a.ldo = ldo;
+    a.M = M; a.Nn = Nn; a.Kk = Kk;
+    a.tiles_n = ce_div_up(Nn, TN_BN); a.tiles_k = ce_div_up(Kk, TN_BK);
+    const int m_tiles = ce_div_up(M, TN_BM);
+    if (splits <= 0) {  // fill ~2 workgroups per CU
+        const int tiles = a.tiles_n * a.tiles_k;
+        splits = (512 + tiles - 1) / tiles;
+    }
+    if (splits > m_tiles) splits = m_tiles;
+    if (splits < 1) splits = 1;
+    a.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
+    a.splits = ce_div_up(M, a.m_per_split);
+    CE_CHECK_ARG((long)a.m_per_split * (ldp > ldq ? ldp : ldq) * 2 < (1L << 32), "ce_gemm_tn: split exceeds 4 GiB");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            TN_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k * a.splits), dim3(256), TN_LDS_BYTES,
+                       (hipStream_t)stream, a);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream) {
+    if (shape == 16)
+        hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16x8*)a_frags,
+                           (const bf16x8*)b_frags, (f32x4*)out);
+    else if (shape == 32)
+        hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16x8*)a_frags,
+                           (const bf16x8*)b_frags, (f32x16*)out);
+    else
+        CE_CHECK_ARG(false, "ce_probe_mfma: shape must be 16 or 32");
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_probe_tr16(const void* image, int n_elems, const int* byte_off, void* out, void* stream) {
+    CE_CHECK_ARG(n_elems > 0 && n_elems <= 16384, "ce_probe_tr16: image must hold 1..16384 elements");
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), n_elems * 2, (hipStream_t)stream, (const uint16_t*)image,
+                       n_elems, byte_off, (s16x4*)out);
+    CE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,84 @@
+"""Op-level Python wrappers over the C ABI (used by the tower runner's tests and by the
+loss-head / optimizer code).  Each wrapper only marshals pointers and sizes; all math runs in
+the HIP library.  bf16 tensors are torch.bfloat16, residual/grad streams torch.float32."""
+from __future__ import annotations
+
+from ctypes import c_float, c_int, c_long, c_void_p
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream
+
+
+def _rows(t: torch.Tensor) -> int:
+    return t.shape[0]
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, epilogue: int, *, bias=None, resid=None, out=None, out2=None,
+            aux=None, M: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue (include/clip_event_hip.h)."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.is_cuda and b.is_cuda
+    M = a.shape[0] if M is None else M
+    K = a.shape[1]
+    N = b.shape[0]
+    assert b.shape[1] == K
+    f32_out = epilogue in (L.EPI_F32, L.EPI_BIAS_F32, L.EPI_BIAS_RESID_F32)
+    if out is None:
+        out = torch.empty(a.shape[0], N, device=a.device, dtype=torch.float32 if f32_out else torch.bfloat16)
+    if epilogue == L.EPI_BIAS_GELU and out2 is None:
+        out2 = torch.empty_like(out)
+    check(lib().ce_gemm_nt(ptr(a), c_long(a.stride(0)), ptr(b), c_long(b.stride(0)), c_int(M), c_int(N), c_int(K),
+                           c_int(epilogue), ptr(bias), ptr(resid), c_long(resid.stride(0) if resid is not None else 0),
+                           ptr(out), c_long(out.stride(0)), ptr(out2), c_long(out2.stride(0) if out2 is not None else 0),
+                           ptr(aux), c_long(aux.stride(0) if aux is not None else 0), stream()), "ce_gemm_nt")
+    return (out, out2) if epilogue == L.EPI_BIAS_GELU else out
+
+
+def gemm_tn(p: torch.Tensor, q: torch.Tensor, out: torch.Tensor, splits: int = 0, M: Optional[int] = None):
+    """out[Nn,Kk] += p[M,Nn]^T @ q[M,Kk] (fp32 atomic accumulation)."""
+    assert p.dtype == torch.bfloat16 and q.dtype == torch.bfloat16 and out.dtype == torch.float32
+    M = p.shape[0] if M is None else M
+    check(lib().ce_gemm_tn(ptr(p), c_long(p.stride(0)), ptr(q), c_long(q.stride(0)), c_int(M), c_int(p.shape[1]),
+                           c_int(q.shape[1]), ptr(out), c_long(out.stride(0)), c_int(splits), stream()), "ce_gemm_tn")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, w, b, *, rows=None, out_f32=False, eps=1e-5, M=None):
+    """y = LN(x[rows]) ; returns (y, mean, rstd)."""
+    assert x.dtype == torch.float32
+    M = (rows.shape[0] if rows is not None else x.shape[0]) if M is None else M
+    D = x.shape[-1]
+    y = torch.empty(M, D, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(lib().ce_layernorm_fwd(ptr(x), c_long(x.stride(0)), ptr(rows), ptr(w), ptr(b), ptr(y), c_long(y.stride(0)),
+                                 c_int(1 if out_f32 else 0), ptr(mean), ptr(rstd), c_int(M), c_int(D), c_float(eps),
+                                 stream()), "ce_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, rows=None, dx_in=None, dx_out=None, dxb=None):
+    """dx_out = dx_in + LN'(dy); dxb = bf16(dx_out); dw += ..., db += ... (atomic)."""
+    M = dy.shape[0]
+    D = dy.shape[1]
+    if dx_out is None:
+        dx_out = torch.zeros_like(x) if rows is not None else torch.empty_like(x)
+    check(lib().ce_layernorm_bwd(ptr(dy), c_long(dy.stride(0)), c_int(1 if dy.dtype == torch.float32 else 0), ptr(x),
+                                 c_long(x.stride(0)), ptr(rows), ptr(mean), ptr(rstd), ptr(w), ptr(dx_in), ptr(dx_out),
+                                 c_long(dx_out.stride(0)), ptr(dxb), c_long(dxb.stride(0) if dxb is not None else 0),
+                                 ptr(dw), ptr(db), c_int(M), c_int(D), stream()), "ce_layernorm_bwd")
+    return dx_out
+
+
+def probe_mfma(shape: int, a_frags: torch.Tensor, b_frags: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(64, 4 if shape == 16 else 16, device=a_frags.device, dtype=torch.float32)
+    check(lib().ce_probe_mfma(c_int(shape), ptr(a_frags), ptr(b_frags), ptr(out), stream()), "ce_probe_mfma")
+    return out
+
+
+def probe_tr16(image: torch.Tensor, byte_off: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(64, 4, device=image.device, dtype=torch.int16)
+    check(lib().ce_probe_tr16(ptr(image), c_int(image.numel()), ptr(byte_off), ptr(out), stream()), "ce_probe_tr16")
+    return out

@@ -1,0 +1,136 @@
+"""GPU parity of the op-level HIP kernels (through the C ABI) against plain PyTorch fp32 on
+the same bf16-rounded inputs.  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _randn(rng, *shape, scale=1.0):
+    return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * scale)
+
+
+def _report(name, got, exp):
+    got, exp = got.double().cpu(), exp.double().cpu()
+    err = (got - exp).abs().max().item()
+    rel = ((got - exp).norm() / (exp.norm() + 1e-30)).item()
+    print(f"[{name}] max_abs_err={err:.3e} rel_l2={rel:.3e} ref_rms={exp.pow(2).mean().sqrt().item():.3e}")
+    return err, rel
+
+
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (400, 768, 512), (77, 512, 2048), (20, 64, 128), (1000, 2304, 768),
+               (130, 132, 72)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_bf16_and_f32(M, N, K):
+    from clip_event_amd import ops, _lib as L
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    out32 = ops.gemm_nt(a.to(DEV), b.to(DEV), L.EPI_F32)
+    torch.cuda.synchronize()
+    err, rel = _report(f"nt f32 {M}x{N}x{K}", out32, ref)
+    assert rel < 1e-5          # fp32 accumulation of exact bf16 products: only summation order differs
+    out16 = ops.gemm_nt(a.to(DEV), b.to(DEV), L.EPI_BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(out16.cpu(), out32.cpu().to(torch.bfloat16))
+
+
+def test_gemm_nt_epilogues():
+    from clip_event_amd import ops, _lib as L
+    M, N, K = 400, 512, 256
+    rng = np.random.default_rng(5)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    bias = _randn(rng, N)
+    resid = _randn(rng, M, N)
+    aux = _randn(rng, M, N).to(torch.bfloat16)
+    acc = a.float() @ b.float().t()
+    A, B = a.to(DEV), b.to(DEV)
+    o = ops.gemm_nt(A, B, L.EPI_BIAS_BF16, bias=bias.to(DEV)).float().cpu()
+    assert _report("bias_bf16", o, (acc + bias).to(torch.bfloat16).float())[1] < 3e-3
+    o = ops.gemm_nt(A, B, L.EPI_BIAS_F32, bias=bias.to(DEV)).cpu()
+    assert _report("bias_f32", o, acc + bias)[1] < 1e-5
+    o = ops.gemm_nt(A, B, L.EPI_BIAS_RESID_F32, bias=bias.to(DEV), resid=resid.to(DEV)).cpu()
+    assert _report("bias_resid", o, acc + bias + resid)[1] < 1e-5
+    pre, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+    h = acc + bias
+    assert _report("gelu pre", pre.float().cpu(), h)[1] < 3e-3
+    assert _report("gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
+    o = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV)).float().cpu()
+    x = aux.float()
+    s = torch.sigmoid(1.702 * x)
+    assert _report("gelugrad", o, acc * (s * (1 + 1.702 * x * (1 - s))))[1] < 3e-3
+
+
+TN_SHAPES = [(64, 128, 128), (256, 256, 384), (1000, 768, 512), (77 * 8, 512, 2048), (50, 64, 72), (12800, 768, 768)]
+
+
+@pytest.mark.parametrize("M,Nn,Kk", TN_SHAPES)
+def test_gemm_tn(M, Nn, Kk):
+    from clip_event_amd import ops
+    rng = np.random.default_rng(M + Nn + Kk)
+    p = _randn(rng, M, Nn).to(torch.bfloat16)
+    q = _randn(rng, M, Kk, scale=M ** -0.5).to(torch.bfloat16)
+    ref = p.float().t() @ q.float()
+    base = _randn(rng, Nn, Kk)
+    for splits in (0, 1):
+        out = base.clone().to(DEV)
+        ops.gemm_tn(p.to(DEV), q.to(DEV), out, splits=splits)
+        torch.cuda.synchronize()
+        err, rel = _report(f"tn {M}x{Nn}x{Kk} splits={splits}", out.cpu() - base, ref)
+        assert rel < 2e-5
+
+
+@pytest.mark.parametrize("M,D", [(7, 128), (400, 768), (616, 512), (33, 1024), (5, 64)])
+def test_layernorm_fwd_bwd(M, D):
+    from clip_event_amd import ops
+    rng = np.random.default_rng(M * 13 + D)
+    x = (_randn(rng, M, D) * 2 + 0.5).requires_grad_(True)
+    w = (1 + 0.1 * _randn(rng, D)).requires_grad_(True)
+    b = (0.1 * _randn(rng, D)).requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV))
+    assert _report("ln fwd bf16", y.float().cpu(), y_ref.detach().to(torch.bfloat16).float())[1] < 3e-3
+    y32, _, _ = ops.layernorm_fwd(x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), out_f32=True)
+    assert _report("ln fwd f32", y32.cpu(), y_ref.detach())[1] < 2e-6
+    dy = _randn(rng, M, D).to(torch.bfloat16)
+    dx_in = _randn(rng, M, D)
+    y_ref.backward(dy.float())
+    dw = torch.zeros(D, device=DEV)
+    db = torch.zeros(D, device=DEV)
+    dxb = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), mean, rstd, w.detach().to(DEV), dw, db,
+                           dx_in=dx_in.to(DEV), dxb=dxb)
+    torch.cuda.synchronize()
+    assert _report("ln dx", dx.cpu(), x.grad + dx_in)[1] < 1e-5
+    assert torch.equal(dxb.cpu(), dx.cpu().to(torch.bfloat16))
+    assert _report("ln dw", dw.cpu(), w.grad)[1] < 1e-5
+    assert _report("ln db", db.cpu(), b.grad)[1] < 1e-5
+
+
+def test_layernorm_row_gather_scatter():
+    from clip_event_amd import ops
+    rng = np.random.default_rng(3)
+    B, Ltok, D = 6, 5, 128
+    x = _randn(rng, B * Ltok, D)
+    w = 1 + 0.1 * _randn(rng, D)
+    b = 0.1 * _randn(rng, D)
+    rows = (torch.arange(B) * Ltok + torch.tensor([0, 1, 4, 2, 3, 0])).to(torch.int32)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), rows=rows.to(DEV), out_f32=True)
+    ref = torch.nn.functional.layer_norm(x[rows.long()], (D,), w, b, 1e-5)
+    assert _report("ln gather", y.cpu(), ref)[1] < 2e-6
+    dy = _randn(rng, B, D)
+    xs = x[rows.long()].clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xs, (D,), w, b, 1e-5).backward(dy)
+    dw = torch.zeros(D, device=DEV)
+    db = torch.zeros(D, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, w.to(DEV), dw, db, rows=rows.to(DEV))
+    full = torch.zeros(B * Ltok, D)
+    full[rows.long()] = xs.grad
+    assert _report("ln scatter dx", dx.cpu(), full)[1] < 1e-5
