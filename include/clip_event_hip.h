@@ -53,6 +53,27 @@ int ce_gemm_nt(const void* A, long lda, const void* B, long ldb, int M, int N, i
 int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out, long ldo,
                int splits, void* stream);
 
+/* y = LayerNorm(x[rows[r]] or x[r]) over D columns, fp32 statistics (eps inside the sqrt).
+ * y is bf16 (out_f32=0: the next GEMM's operand) or fp32 (ln_pre: the residual stream).
+ * Writes mean/rstd [M] for the backward.  Replaces LayerNorm.forward, model_clip.py:157-163. */
+int ce_layernorm_fwd(const float* x, long ldx, const int* rows, const float* w, const float* b, void* y, long ldy,
+                     int out_f32, float* mean, float* rstd, int M, int D, float eps, void* stream);
+
+/* dx_out[dst] = (dx_in ? dx_in[dst] : 0) + dLN(dy[r]); dst = rows ? rows[r] : r; dxb = bf16 copy
+ * (nullable); dw/db (f32 [D]) accumulate atomically (caller zeroes once per step). */
+int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const float* x, long ldx, const int* rows,
+                     const float* mean, const float* rstd, const float* w, const float* dx_in, float* dx_out,
+                     long lddx, void* dxb, long lddxb, float* dw, float* db, int M, int D, void* stream);
+
+/* Self-attention core on the packed in-projection output qkv[B*L, 3*H*64] (bf16; q | k | v column
+ * blocks, head h at columns h*64): o[B*L, H*64] = softmax(q k^T / 8 + causal?) v, lse[B*H*L] (f32)
+ * saved for the backward.  L <= 128.  Replaces the core of nn.MultiheadAttention as called at
+ * model_clip.py:188 (mask from model_clip.py:377-384). */
+int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, int B, int L, int H, int causal,
+                     void* stream);
+int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
+                     const float* lse, void* dqkv, long lddq, int B, int L, int H, int causal, void* stream);
+
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);
 int ce_probe_tr16(const void* image, int n_elems, const int* byte_off, void* out, void* stream);

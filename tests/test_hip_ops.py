@@ -134,3 +134,37 @@ def test_layernorm_row_gather_scatter():
     full = torch.zeros(B * Ltok, D)
     full[rows.long()] = xs.grad
     assert _report("ln scatter dx", dx.cpu(), full)[1] < 1e-5
+
+
+def _attn_ref(qkv, B, L, H, causal):
+    D = H * 64
+    q, k, v = qkv.float().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)      # [B,H,L,64] each
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.triu(torch.full((L, L), float("-inf")), diagonal=1)
+    a = torch.softmax(s, dim=-1)
+    o = (a @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(3, 50, 12, False), (2, 77, 8, True), (4, 5, 2, False), (3, 20, 2, True),
+                                          (2, 128, 2, True), (1, 16, 1, False), (2, 33, 3, True)])
+def test_attention_fwd_bwd(B, L, H, causal):
+    from clip_event_amd import ops
+    rng = np.random.default_rng(B * 100 + L)
+    D = H * 64
+    qkv = _randn(rng, B * L, 3 * D).to(torch.bfloat16)
+    qkv_r = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qkv_r, B, L, H, causal)
+    o, lse = ops.attention_fwd(qkv.to(DEV), B, L, H, causal)
+    torch.cuda.synchronize()
+    # bf16 P and bf16 output rounding: ~2^-8 relative
+    assert _report(f"attn fwd o L={L}", o.float().cpu(), o_ref.detach())[1] < 1e-2
+    assert _report("attn lse", lse.cpu().view(B, H, L), lse_ref.detach())[0] < 1e-3
+    dout = _randn(rng, B * L, D).to(torch.bfloat16)
+    o_ref.backward(dout.float())
+    dqkv = ops.attention_bwd(qkv.to(DEV), o, dout.to(DEV), lse, B, L, H, causal)
+    torch.cuda.synchronize()
+    g = qkv_r.grad
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _report(f"attn {name} L={L}", dqkv[:, sl].float().cpu(), g[:, sl])[1] < 2e-2
