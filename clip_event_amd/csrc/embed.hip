@@ -1,0 +1,292 @@
+// Input-side and bookkeeping kernels of the two towers (gfx950): all HBM-bound, vectorised
+// 16-byte accesses, no inter-workgroup communication except final float atomics.
+//
+//   ce_im2col            image fp32 NCHW -> bf16 patch rows      (Conv2d k=s=patch, model_clip.py:219,235)
+//   ce_vision_assemble   [cls | patches] + positional embedding   (model_clip.py:237-242)
+//   ce_vision_assemble_bwd
+//   ce_token_embed       token_embedding[ids] + positional        (model_clip.py:400-403)
+//   ce_token_embed_bwd   scatter-add into the embedding gradient
+//   ce_batch_reduce      sum over the batch axis (positional / class embedding gradients)
+//   ce_colsum_bf16       bias gradients (column sums of a bf16 activation gradient)
+//   ce_cast_transpose    fp32 master weight -> bf16 copy + bf16 transposed copy
+//   ce_cast_bf16         fp32 -> bf16
+//   ce_eot_rows          argmax token id per row -> flat row index (model_clip.py:415)
+#include "common.hpp"
+#include "../../include/clip_event_hip.h"
+
+namespace {
+
+// one thread = 8 consecutive output columns of one patch row
+__global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int R, int ps, int grid,
+                              int Kp) {
+    const long total = (long)B * grid * grid * (Kp / 8);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % (Kp / 8));
+        const long row = idx / (Kp / 8);
+        const int gx = (int)(row % grid), gy = (int)((row / grid) % grid), b = (int)(row / ((long)grid * grid));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = cg * 8 + e;
+            float val = 0.f;
+            if (col < 3 * ps * ps) {
+                const int c = col / (ps * ps), py = (col / ps) % ps, px = col % ps;
+                val = img[(((long)b * 3 + c) * R + gy * ps + py) * R + gx * ps + px];
+            }
+            v[e] = val;
+        }
+        u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(out + row * Kp + cg * 8) = pk;
+    }
+}
+
+// x0[b, t, :] = (t == 0 ? cls : patch[b*P + t-1, :]) + pos[t, :]      (fp32, 4 columns per thread)
+__global__ void vision_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                       const float* __restrict__ pos, float* __restrict__ x0, int B, int Ltok, int D) {
+    const long total = (long)B * Ltok * (D / 4);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % (D / 4)) * 4;
+        const long row = idx / (D / 4);
+        const int t = (int)(row % Ltok);
+        const long b = row / Ltok;
+        f32x4 v = (t == 0) ? *reinterpret_cast<const f32x4*>(cls + c)
+                           : *reinterpret_cast<const f32x4*>(patch + (b * (Ltok - 1) + t - 1) * D + c);
+        v += *reinterpret_cast<const f32x4*>(pos + (long)t * D + c);
+        *reinterpret_cast<f32x4*>(x0 + row * D + c) = v;
+    }
+}
+
+// dpatch (bf16) [B*P, D] = dx0[b, 1+p, :]
+__global__ void vision_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t* __restrict__ dpatch, int B, int Ltok,
+                                           int D) {
+    const long total = (long)B * (Ltok - 1) * (D / 4);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % (D / 4)) * 4;
+        const long row = idx / (D / 4);
+        const long b = row / (Ltok - 1);
+        const int p = (int)(row % (Ltok - 1));
+        f32x4 v = *reinterpret_cast<const f32x4*>(dx0 + (b * Ltok + p + 1) * D + c);
+        u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(dpatch + row * D + c) = pk;
+    }
+}
+
+__global__ void token_embed_kernel(const long* __restrict__ ids, const float* __restrict__ table,
+                                   const float* __restrict__ pos, float* __restrict__ x0, long rows, int Ltok, int D,
+                                   int vocab) {
+    const long total = rows * (D / 4);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % (D / 4)) * 4;
+        const long row = idx / (D / 4);
+        long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // ids are validated on the host; clamp keeps the access in bounds
+        f32x4 v = *reinterpret_cast<const f32x4*>(table + id * D + c);
+        v += *reinterpret_cast<const f32x4*>(pos + (long)(row % Ltok) * D + c);
+        *reinterpret_cast<f32x4*>(x0 + row * D + c) = v;
+    }
+}
+
+// dtable[ids[row], :] += dx0[row, :]   one wave-instruction = 256 contiguous bytes of one row
+__global__ void token_embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dx0,
+                                       float* __restrict__ dtable, long rows, int D, int vocab) {
+    const long total = rows * D;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / D;
+        const int c = (int)(idx % D);
+        long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        atomicAdd(dtable + id * D + c, dx0[idx]);
+    }
+}
+
+// out[t, c] (+)= sum_b x[b, t, c]  over `B` slabs of `slab` floats, rows [row0, row0+nrows) of each slab
+__global__ void batch_reduce_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long slab, long n,
+                                    int accumulate) {
+    const long i4 = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (long)b * slab + i4);
+        f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (long)(b + 1) * slab + i4);
+        f32x4 a2 = *reinterpret_cast<const f32x4*>(x + (long)(b + 2) * slab + i4);
+        f32x4 a3 = *reinterpret_cast<const f32x4*>(x + (long)(b + 3) * slab + i4);
+        acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < B; ++b) acc += *reinterpret_cast<const f32x4*>(x + (long)b * slab + i4);
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(out + i4);
+    *reinterpret_cast<f32x4*>(out + i4) = acc;
+}
+
+// out[n] += sum_m x[m, n] ; block = 4 waves over different rows of the same 256 columns
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ out,
+                                                          int M, int N) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        for (int r = blockIdx.y * 4 + wave; r < M; r += gridDim.y * 4) {
+            u32x2 pk = *reinterpret_cast<const u32x2*>(x + (long)r * ld + c);
+            acc += f32x4{bf_lo(pk[0]), bf_hi(pk[0]), bf_lo(pk[1]), bf_hi(pk[1])};
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < N) {
+        f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, t[e]);
+    }
+}
+
+// w[R, C] fp32 -> w16[R, C] bf16 and w16t[C, R] bf16 through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ w16,
+                                                             long ld16, bf16_t* __restrict__ w16t, long ld16t, int R,
+                                                             int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = (r < R && c < C) ? w[(long)r * C + c] : 0.f;
+        tile[ty + 8 * k][tx] = v;
+        if (w16 && r < R && c < C) w16[(long)r * ld16 + c] = f2bf(v);
+    }
+    __syncthreads();
+    if (w16t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < R && c < C) w16t[(long)c * ld16t + r] = f2bf(tile[tx][ty + 8 * k]);
+        }
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+    const long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(y + i) = pk;
+    } else {
+        for (long k = i; k < n; ++k) y[k] = f2bf(x[k]);
+    }
+}
+
+// rows[r] = r*Ltok + argmax_t ids[r, t]  (first maximum, like torch.argmax on these rows)
+__global__ void eot_rows_kernel(const long* __restrict__ ids, int* __restrict__ rows, long n, int Ltok) {
+    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    long best = ids[r * Ltok];
+    int arg = 0;
+    for (int t = 1; t < Ltok; ++t) {
+        const long v = ids[r * Ltok + t];
+        if (v > best) {
+            best = v;
+            arg = t;
+        }
+    }
+    rows[r] = (int)(r * Ltok + arg);
+}
+
+int grid_for(long threads, int block = 256, int cap = 8192) {
+    long g = (threads + block - 1) / block;
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int ce_im2col(const float* image, void* patches, int B, int resolution, int patch, int k_padded,
+                         void* stream) {
+    CE_CHECK_ARG(B > 0 && patch > 0 && resolution % patch == 0, "ce_im2col: resolution %d not a multiple of patch %d", resolution, patch);
+    CE_CHECK_ARG(k_padded % 8 == 0 && k_padded >= 3 * patch * patch, "ce_im2col: k_padded must be a multiple of 8 >= 3*patch^2");
+    const int grid = resolution / patch;
+    const long threads = (long)B * grid * grid * (k_padded / 8);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(threads)), dim3(256), 0, (hipStream_t)stream, image,
+                       (bf16_t*)patches, B, resolution, patch, grid, k_padded);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_vision_assemble(const float* patch_out, const float* cls, const float* pos, float* x0, int B,
+                                  int tokens, int D, void* stream) {
+    CE_CHECK_ARG(B > 0 && tokens > 1 && D % 4 == 0, "ce_vision_assemble: bad shape");
+    hipLaunchKernelGGL(vision_assemble_kernel, dim3(grid_for((long)B * tokens * (D / 4))), dim3(256), 0,
+                       (hipStream_t)stream, patch_out, cls, pos, x0, B, tokens, D);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_vision_assemble_bwd(const float* dx0, void* dpatch, int B, int tokens, int D, void* stream) {
+    CE_CHECK_ARG(B > 0 && tokens > 1 && D % 4 == 0, "ce_vision_assemble_bwd: bad shape");
+    hipLaunchKernelGGL(vision_assemble_bwd_kernel, dim3(grid_for((long)B * (tokens - 1) * (D / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dx0, (bf16_t*)dpatch, B, tokens, D);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_token_embed(const int64_t* ids, const float* table, const float* pos, float* x0, long rows,
+                              int tokens, int D, int vocab, void* stream) {
+    CE_CHECK_ARG(rows > 0 && tokens > 0 && D % 4 == 0 && vocab > 0, "ce_token_embed: bad shape");
+    hipLaunchKernelGGL(token_embed_kernel, dim3(grid_for(rows * (D / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)ids, table, pos, x0, rows, tokens, D, vocab);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_token_embed_bwd(const int64_t* ids, const float* dx0, float* dtable, long rows, int D, int vocab,
+                                  void* stream) {
+    CE_CHECK_ARG(rows > 0 && D > 0 && vocab > 0, "ce_token_embed_bwd: bad shape");
+    hipLaunchKernelGGL(token_embed_bwd_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)ids, dx0, dtable, rows, D, vocab);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_batch_reduce(const float* x, float* out, int B, long slab, long n, int accumulate, void* stream) {
+    CE_CHECK_ARG(B > 0 && n > 0 && n % 4 == 0 && slab % 4 == 0 && n <= slab, "ce_batch_reduce: bad shape");
+    hipLaunchKernelGGL(batch_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       out, B, slab, n, accumulate);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_colsum_bf16(const void* x, long ld, float* out, int M, int N, void* stream) {
+    CE_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "ce_colsum_bf16: bad shape");
+    const int gx = ce_div_up(N, 256);
+    int gy = ce_div_up(M, 4 * 16);
+    const int cap = (1024 + gx - 1) / gx;
+    if (gy > cap) gy = cap;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, M,
+                       N);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_cast_transpose(const float* w, void* w16, long ld16, void* w16t, long ld16t, int R, int C,
+                                 void* stream) {
+    CE_CHECK_ARG(R > 0 && C > 0, "ce_cast_transpose: bad shape");
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(ce_div_up(C, 32), ce_div_up(R, 32)), dim3(256), 0, (hipStream_t)stream,
+                       w, (bf16_t*)w16, ld16, (bf16_t*)w16t, ld16t, R, C);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_cast_bf16(const float* x, void* y, long n, void* stream) {
+    CE_CHECK_ARG(n > 0, "ce_cast_bf16: empty");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16_t*)y, n);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_eot_rows(const int64_t* ids, int* rows, long n, int tokens, void* stream) {
+    CE_CHECK_ARG(n > 0 && tokens > 0, "ce_eot_rows: bad shape");
+    hipLaunchKernelGGL(eot_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)ids, rows, n, tokens);
+    CE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,95 @@
+// Fused optimiser step over the flat fp32 parameter / gradient buffers (gfx950, HBM-bound).
+//
+// Replaces engine.py:89-90: torch.nn.utils.clip_grad_norm_(params, 1) followed by
+// torch.optim.Adam(lr, weight_decay).step() (L2 weight decay, not AdamW; engine.py:141-146).
+// Two launches per step instead of ~900: a sum-of-squares reduction into a device scalar,
+// then one Adam pass that reads the scalar (no host sync) and applies the clip coefficient
+// max_norm / (norm + 1e-6) (clamped to 1) on the fly.
+#include "common.hpp"
+#include "../../include/clip_event_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long stride = gridDim.x * 1024L;
+    for (long i = blockIdx.x * 1024L + threadIdx.x * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+            s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        } else {
+            for (long k = i; k < n; ++k) s += g[k] * g[k];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const float* __restrict__ sumsq, float max_norm, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    float coef = 1.0f;
+    if (sumsq) {
+        const float norm = sqrtf(*sumsq);
+        coef = fminf(1.0f, max_norm / (norm + 1e-6f));
+    }
+    const long stride = gridDim.x * 1024L;
+    for (long i = blockIdx.x * 1024L + threadIdx.x * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+            f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * coef;
+            f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
+            f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+            if (wd != 0.f) gv += pv * wd;
+            mv = mv * b1 + gv * (1.0f - b1);
+            vv = vv * b2 + gv * gv * (1.0f - b2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+                pv[e] -= (lr / bc1) * (mv[e] / denom);
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            for (long k = i; k < n; ++k) {
+                float gk = g[k] * coef;
+                if (wd != 0.f) gk += p[k] * wd;
+                const float mk = m[k] * b1 + gk * (1.0f - b1);
+                const float vk = v[k] * b2 + gk * gk * (1.0f - b2);
+                p[k] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+                m[k] = mk;
+                v[k] = vk;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ce_sumsq(const float* g, long n, float* out, void* stream) {
+    CE_CHECK_ARG(n > 0, "ce_sumsq: empty");
+    long blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float max_norm,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                            void* stream) {
+    CE_CHECK_ARG(n > 0 && step >= 1, "ce_adam_step: need n>0 and step>=1");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    long blocks = (n + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq,
+                       max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+    CE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,301 @@
+"""Coarse autograd nodes of the HIP path: one per tower pass, one for the logits.
+
+Each ``forward`` issues the HIP launches through the C ABI and keeps the activation stash
+(a leased workspace carved by the C++ tower runner); each ``backward`` runs the HIP backward
+and accumulates parameter gradients directly into the model's flat gradient buffer (the
+``nn.Parameter.grad`` views), returning ``None`` for the trigger input that only exists to put
+the node on the autograd tape.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_long, c_void_p
+
+import torch
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def _tower_workspace(model, desc, batch: int, tag: str):
+    from .model import _Lease
+    nbytes = lib().ce_tower_workspace_bytes(ctypes.byref(desc), c_int(batch))
+    if nbytes == 0:
+        raise RuntimeError("ce_tower_workspace_bytes: " + lib().ce_last_error().decode())
+    buf = model._pool.take(tag, int(nbytes), model._flat.device)
+    return _Lease(model._pool, tag, buf)
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class EncodeImageFn(torch.autograd.Function):
+    """VisualTransformer.forward (model_clip.py:232-263) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, image, trigger, model, use_grid: bool):
+        cl, s = lib(), stream()
+        v = model.visual
+        dev = model._flat.device
+        if image.device != dev:
+            raise RuntimeError("image must live on the model's GPU")
+        image = _f32(image)                                   # image.type(self.dtype), model_clip.py:391
+        B = image.shape[0]
+        R, ps, g, D, E = v.input_resolution, v.patch_size, v.patch_num, model.vision_width, model.embed_dim
+        if tuple(image.shape[1:]) != (3, R, R):
+            raise RuntimeError(f"expected image [B,3,{R},{R}], got {tuple(image.shape)}")
+        T = g * g + 1
+        M = B * T
+        P = model._pmap
+        patches = _empty((B * g * g, model._kp), torch.bfloat16, dev)
+        check(cl.ce_im2col(ptr(image), ptr(patches), c_int(B), c_int(R), c_int(ps), c_int(model._kp), s), "ce_im2col")
+        patch_out = _empty((B * g * g, D), torch.float32, dev)
+        wconv = model._w16["visual.conv1.weight"]
+        check(cl.ce_gemm_nt(ptr(patches), c_long(model._kp), ptr(wconv), c_long(model._kp), c_int(B * g * g), c_int(D),
+                            c_int(model._kp), c_int(L.EPI_F32), None, None, c_long(0), ptr(patch_out), c_long(D), None,
+                            c_long(0), None, c_long(0), s), "ce_gemm_nt(conv1)")
+        xpre = _empty((M, D), torch.float32, dev)
+        check(cl.ce_vision_assemble(ptr(patch_out), ptr(P["visual.class_embedding"]), ptr(P["visual.positional_embedding"]),
+                                    ptr(xpre), c_int(B), c_int(T), c_int(D), s), "ce_vision_assemble")
+        x0 = _empty((M, D), torch.float32, dev)
+        mean_pre, rstd_pre = _empty((M,), torch.float32, dev), _empty((M,), torch.float32, dev)
+        check(cl.ce_layernorm_fwd(ptr(xpre), c_long(D), None, ptr(P["visual.ln_pre.weight"]), ptr(P["visual.ln_pre.bias"]),
+                                  ptr(x0), c_long(D), c_int(1), ptr(mean_pre), ptr(rstd_pre), c_int(M), c_int(D),
+                                  c_float(1e-5), s), "ce_layernorm_fwd(ln_pre)")
+        lease = _tower_workspace(model, model._vdesc, B, "vision")
+        xN = _empty((M, D), torch.float32, dev)
+        check(cl.ce_tower_forward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(xN), s),
+              "ce_tower_forward(vision)")
+        if use_grid:
+            rows, n = None, M
+        else:
+            rows = (torch.arange(B, device=dev, dtype=torch.int32) * T)
+            n = B
+        hpost = _empty((n, D), torch.bfloat16, dev)
+        mean_post, rstd_post = _empty((n,), torch.float32, dev), _empty((n,), torch.float32, dev)
+        check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), ptr(rows), ptr(P["visual.ln_post.weight"]),
+                                  ptr(P["visual.ln_post.bias"]), ptr(hpost), c_long(D), c_int(0), ptr(mean_post),
+                                  ptr(rstd_post), c_int(n), c_int(D), c_float(1e-5), s), "ce_layernorm_fwd(ln_post)")
+        feat = _empty((n, E), torch.float32, dev)
+        wp = model._w16t["visual.proj"]                       # [E, D]: features = hpost @ proj
+        check(cl.ce_gemm_nt(ptr(hpost), c_long(D), ptr(wp), c_long(D), c_int(n), c_int(E), c_int(D), c_int(L.EPI_F32),
+                            None, None, c_long(0), ptr(feat), c_long(E), None, c_long(0), None, c_long(0), s),
+              "ce_gemm_nt(visual.proj)")
+        ctx.model, ctx.lease, ctx.use_grid, ctx.B = model, lease, use_grid, B
+        ctx.saved = (patches, xpre, mean_pre, rstd_pre, x0, xN, rows, hpost, mean_post, rstd_post)
+        return feat.view(B, T, E) if use_grid else feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        model, lease = ctx.model, ctx.lease
+        if lease.buf is None:
+            raise RuntimeError("backward through encode_image a second time: the activation stash was released")
+        cl, s = lib(), stream()
+        patches, xpre, mean_pre, rstd_pre, x0, xN, rows, hpost, mean_post, rstd_post = ctx.saved
+        v = model.visual
+        dev = model._flat.device
+        B, g, D, E = ctx.B, v.patch_num, model.vision_width, model.embed_dim
+        T = g * g + 1
+        M = B * T
+        n = M if ctx.use_grid else B
+        model._attach_grads()
+        P, G = model._pmap, model._gview
+        dfeat = _f32(dfeat).reshape(n, E)
+        dfb = _empty((n, E), torch.bfloat16, dev)
+        check(cl.ce_cast_bf16(ptr(dfeat), ptr(dfb), c_long(n * E), s), "ce_cast_bf16")
+        # features = hpost @ proj  ->  dhpost = dF proj^T ; dproj += hpost^T dF
+        dh = _empty((n, D), torch.bfloat16, dev)
+        check(cl.ce_gemm_nt(ptr(dfb), c_long(E), ptr(model._w16["visual.proj"]), c_long(E), c_int(n), c_int(D), c_int(E),
+                            c_int(L.EPI_BF16), None, None, c_long(0), ptr(dh), c_long(D), None, c_long(0), None,
+                            c_long(0), s), "ce_gemm_nt(dproj)")
+        check(cl.ce_gemm_tn(ptr(hpost), c_long(D), ptr(dfb), c_long(E), c_int(n), c_int(D), c_int(E),
+                            ptr(G("visual.proj")), c_long(E), c_int(0), s), "ce_gemm_tn(visual.proj)")
+        dx = torch.zeros((M, D), dtype=torch.float32, device=dev) if rows is not None else _empty((M, D), torch.float32, dev)
+        check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), ptr(rows), ptr(mean_post),
+                                  ptr(rstd_post), ptr(P["visual.ln_post.weight"]), None, ptr(dx), c_long(D), None,
+                                  c_long(0), ptr(G("visual.ln_post.weight")), ptr(G("visual.ln_post.bias")), c_int(n),
+                                  c_int(D), s), "ce_layernorm_bwd(ln_post)")
+        check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), s),
+              "ce_tower_backward(vision)")
+        lease.release()
+        # ln_pre: x0 = LN(xpre)
+        dxpre = _empty((M, D), torch.float32, dev)
+        check(cl.ce_layernorm_bwd(ptr(dx), c_long(D), c_int(1), ptr(xpre), c_long(D), None, ptr(mean_pre), ptr(rstd_pre),
+                                  ptr(P["visual.ln_pre.weight"]), None, ptr(dxpre), c_long(D), None, c_long(0),
+                                  ptr(G("visual.ln_pre.weight")), ptr(G("visual.ln_pre.bias")), c_int(M), c_int(D), s),
+              "ce_layernorm_bwd(ln_pre)")
+        # positional / class embedding gradients: sums over the batch axis
+        check(cl.ce_batch_reduce(ptr(dxpre), ptr(G("visual.positional_embedding")), c_int(B), c_long(T * D),
+                                 c_long(T * D), c_int(1), s), "ce_batch_reduce(pos)")
+        check(cl.ce_batch_reduce(ptr(dxpre), ptr(G("visual.class_embedding")), c_int(B), c_long(T * D), c_long(D),
+                                 c_int(1), s), "ce_batch_reduce(cls)")
+        # conv1 weight gradient: dW[width, 3*p*p] += dpatch^T patches   (no input gradient is ever needed)
+        dpatch = _empty((B * g * g, D), torch.bfloat16, dev)
+        check(cl.ce_vision_assemble_bwd(ptr(dxpre), ptr(dpatch), c_int(B), c_int(T), c_int(D), s), "ce_vision_assemble_bwd")
+        check(cl.ce_gemm_tn(ptr(dpatch), c_long(D), ptr(patches), c_long(model._kp), c_int(B * g * g), c_int(D),
+                            c_int(model._kp), ptr(G("visual.conv1.weight")), c_long(model._kp), c_int(0), s),
+              "ce_gemm_tn(conv1)")
+        if model.grad_sync is not None:
+            model.grad_sync(model, "visual")
+        return None, None, None, None
+
+
+class EncodeTextFn(torch.autograd.Function):
+    """CLIP.encode_text (model_clip.py:398-417) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, text, trigger, model):
+        cl, s = lib(), stream()
+        dev = model._flat.device
+        if text.device != dev:
+            raise RuntimeError("text must live on the model's GPU")
+        if text.dtype != torch.int64:
+            text = text.long()
+        text = text.contiguous()
+        n, T = text.shape
+        if T != model.context_length:
+            raise RuntimeError(f"expected {model.context_length} tokens per row, got {T}")
+        D, E = model.transformer.width, model.embed_dim
+        M = n * T
+        P = model._pmap
+        x0 = _empty((M, D), torch.float32, dev)
+        check(cl.ce_token_embed(ptr(text), ptr(P["token_embedding.weight"]), ptr(P["positional_embedding"]), ptr(x0),
+                                c_long(M), c_int(T), c_int(D), c_int(model.vocab_size), s), "ce_token_embed")
+        lease = _tower_workspace(model, model._tdesc, n, "text")
+        xN = _empty((M, D), torch.float32, dev)
+        check(cl.ce_tower_forward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(xN), s),
+              "ce_tower_forward(text)")
+        rows = _empty((n,), torch.int32, dev)
+        check(cl.ce_eot_rows(ptr(text), ptr(rows), c_long(n), c_int(T), s), "ce_eot_rows")
+        hfin = _empty((n, D), torch.bfloat16, dev)
+        mean_f, rstd_f = _empty((n,), torch.float32, dev), _empty((n,), torch.float32, dev)
+        check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), ptr(rows), ptr(P["ln_final.weight"]), ptr(P["ln_final.bias"]),
+                                  ptr(hfin), c_long(D), c_int(0), ptr(mean_f), ptr(rstd_f), c_int(n), c_int(D),
+                                  c_float(1e-5), s), "ce_layernorm_fwd(ln_final)")
+        feat = _empty((n, E), torch.float32, dev)
+        wp = model._w16t["text_projection"]                   # [E, D]
+        check(cl.ce_gemm_nt(ptr(hfin), c_long(D), ptr(wp), c_long(D), c_int(n), c_int(E), c_int(D), c_int(L.EPI_F32),
+                            None, None, c_long(0), ptr(feat), c_long(E), None, c_long(0), None, c_long(0), s),
+              "ce_gemm_nt(text_projection)")
+        ctx.model, ctx.lease, ctx.n = model, lease, n
+        ctx.saved = (text, x0, xN, rows, hfin, mean_f, rstd_f)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        model, lease, n = ctx.model, ctx.lease, ctx.n
+        if lease.buf is None:
+            raise RuntimeError("backward through encode_text a second time: the activation stash was released")
+        cl, s = lib(), stream()
+        text, x0, xN, rows, hfin, mean_f, rstd_f = ctx.saved
+        dev = model._flat.device
+        T, D, E = model.context_length, model.transformer.width, model.embed_dim
+        M = n * T
+        model._attach_grads()
+        P, G = model._pmap, model._gview
+        dfeat = _f32(dfeat)
+        dfb = _empty((n, E), torch.bfloat16, dev)
+        check(cl.ce_cast_bf16(ptr(dfeat), ptr(dfb), c_long(n * E), s), "ce_cast_bf16")
+        dh = _empty((n, D), torch.bfloat16, dev)
+        check(cl.ce_gemm_nt(ptr(dfb), c_long(E), ptr(model._w16["text_projection"]), c_long(E), c_int(n), c_int(D),
+                            c_int(E), c_int(L.EPI_BF16), None, None, c_long(0), ptr(dh), c_long(D), None, c_long(0), None,
+                            c_long(0), s), "ce_gemm_nt(dtext_projection)")
+        check(cl.ce_gemm_tn(ptr(hfin), c_long(D), ptr(dfb), c_long(E), c_int(n), c_int(D), c_int(E),
+                            ptr(G("text_projection")), c_long(E), c_int(0), s), "ce_gemm_tn(text_projection)")
+        dx = torch.zeros((M, D), dtype=torch.float32, device=dev)
+        check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), ptr(rows), ptr(mean_f), ptr(rstd_f),
+                                  ptr(P["ln_final.weight"]), None, ptr(dx), c_long(D), None, c_long(0),
+                                  ptr(G("ln_final.weight")), ptr(G("ln_final.bias")), c_int(n), c_int(D), s),
+              "ce_layernorm_bwd(ln_final)")
+        check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(dx), s),
+              "ce_tower_backward(text)")
+        lease.release()
+        check(cl.ce_batch_reduce(ptr(dx), ptr(G("positional_embedding")), c_int(n), c_long(T * D), c_long(T * D),
+                                 c_int(1), s), "ce_batch_reduce(text pos)")
+        check(cl.ce_token_embed_bwd(ptr(text), ptr(dx), ptr(G("token_embedding.weight")), c_long(M), c_int(D),
+                                    c_int(model.vocab_size), s), "ce_token_embed_bwd")
+        if model.grad_sync is not None:
+            model.grad_sync(model, "text")
+        return None, None, None
+
+
+def _sgemm(A, sam, sak, Bm, sbk, sbn, C, M, N, K, alpha_ptr=None, alpha=1.0, alpha_exp=0, beta=0.0):
+    check(lib().ce_sgemm(ptr(A), c_long(sam), c_long(sak), ptr(Bm), c_long(sbk), c_long(sbn), ptr(C), c_long(C.stride(0)),
+                         c_int(M), c_int(N), c_int(K), ptr(alpha_ptr), c_float(alpha), c_int(alpha_exp), c_float(beta),
+                         stream()), "ce_sgemm")
+
+
+class LogitsFn(torch.autograd.Function):
+    """Feature normalisation + logits (model_clip.py:496-521).  ``text_all`` / ``image_all`` may be
+    larger than the local features (all-gathered global batch): logits_per_image =
+    s * I_local @ T_all^T, logits_per_text = s * T_local @ I_all^T."""
+
+    @staticmethod
+    def forward(ctx, fi, ft, logit_scale, overbatch: bool):
+        cl, s = lib(), stream()
+        dev = fi.device
+        fi, ft = _f32(fi), _f32(ft)
+        B, E = fi.shape
+        N = ft.shape[0]
+        In, Tn = torch.empty_like(fi), torch.empty_like(ft)
+        inv_i, inv_t = _empty((B,), torch.float32, dev), _empty((N,), torch.float32, dev)
+        check(cl.ce_l2norm_fwd(ptr(fi), c_long(E), ptr(In), c_long(E), ptr(inv_i), c_int(B), c_int(E), s), "ce_l2norm_fwd")
+        check(cl.ce_l2norm_fwd(ptr(ft), c_long(E), ptr(Tn), c_long(E), ptr(inv_t), c_int(N), c_int(E), s), "ce_l2norm_fwd")
+        ls = logit_scale.detach().reshape(1)
+        lpt = _empty((N, B), torch.float32, dev)
+        _sgemm(Tn, E, 1, In, 1, E, lpt, N, B, E, alpha_ptr=ls, alpha_exp=1)          # s * T I^T
+        if overbatch:
+            lpi = _empty((B, N), torch.float32, dev)
+            _sgemm(In, E, 1, Tn, 1, E, lpi, B, N, E, alpha_ptr=ls, alpha_exp=1)      # s * I T^T
+        else:
+            if N % B != 0:
+                raise RuntimeError("per-instance logits need the same number of descriptions per image")
+            K = N // B
+            lpi = _empty((B, K), torch.float32, dev)
+            check(cl.ce_instance_logits(ptr(In), ptr(Tn), ptr(ls), ptr(lpi), c_int(B), c_int(K), c_int(E), s),
+                  "ce_instance_logits")
+        ctx.saved = (In, Tn, inv_i, inv_t, ls, lpi, lpt)
+        ctx.overbatch = overbatch
+        return lpi, lpt
+
+    @staticmethod
+    def backward(ctx, dlpi, dlpt):
+        cl, s = lib(), stream()
+        In, Tn, inv_i, inv_t, ls, lpi, lpt = ctx.saved
+        dev = In.device
+        B, E = In.shape
+        N = Tn.shape[0]
+        dIn = torch.zeros_like(In)
+        dTn = torch.zeros_like(Tn)
+        dls = torch.zeros(1, dtype=torch.float32, device=dev)
+        if dlpt is not None:
+            dlpt = _f32(dlpt)
+            # lpt = s T I^T : dT += s dlpt I ; dI += s dlpt^T T
+            _sgemm(dlpt, B, 1, In, E, 1, dTn, N, E, B, alpha_ptr=ls, alpha_exp=1, beta=1.0)
+            _sgemm(dlpt, 1, B, Tn, E, 1, dIn, B, E, N, alpha_ptr=ls, alpha_exp=1, beta=1.0)
+            check(cl.ce_dot(ptr(dlpt), ptr(lpt), c_long(N * B), ptr(dls), s), "ce_dot")
+        if dlpi is not None:
+            dlpi = _f32(dlpi)
+            if ctx.overbatch:
+                _sgemm(dlpi, N, 1, Tn, E, 1, dIn, B, E, N, alpha_ptr=ls, alpha_exp=1, beta=1.0)
+                _sgemm(dlpi, 1, N, In, E, 1, dTn, N, E, B, alpha_ptr=ls, alpha_exp=1, beta=1.0)
+            else:
+                K = N // B
+                check(cl.ce_instance_logits_bwd(ptr(dlpi), ptr(In), ptr(Tn), ptr(ls), ptr(dIn), ptr(dTn), c_int(B),
+                                                c_int(K), c_int(E), s), "ce_instance_logits_bwd")
+            check(cl.ce_dot(ptr(dlpi), ptr(lpi), c_long(dlpi.numel()), ptr(dls), s), "ce_dot")
+        dfi, dft = torch.empty_like(In), torch.empty_like(Tn)
+        check(cl.ce_l2norm_bwd(ptr(dIn), c_long(E), ptr(In), c_long(E), ptr(inv_i), ptr(dfi), c_long(E), c_int(B), c_int(E),
+                               c_int(0), s), "ce_l2norm_bwd")
+        check(cl.ce_l2norm_bwd(ptr(dTn), c_long(E), ptr(Tn), c_long(E), ptr(inv_t), ptr(dft), c_long(E), c_int(N), c_int(E),
+                               c_int(0), s), "ce_l2norm_bwd")
+        return dfi, dft, dls.reshape(()), None
+
+
+def logits_from_features(image_features, text_features, logit_scale, overbatch: bool = True):
+    return LogitsFn.apply(image_features, text_features, logit_scale, bool(overbatch))

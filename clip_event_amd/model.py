@@ -1,0 +1,459 @@
+"""Drop-in for the reference's ``model_clip.CLIP`` / ``build_model`` on MI355X.
+
+Host-side mirror of ``/root/reference/src/clip-event/model_clip.py`` (ViT towers only):
+same constructor signature (incl. the ``constrastive_overbatch`` spelling), attribute names,
+state-dict keys/shapes, ``forward`` / ``encode_image`` / ``encode_text`` / ``sim_entity`` /
+``set_hyps`` behaviour and return arity.  All device math is hand-written HIP behind the C ABI
+(``include/clip_event_hip.h``); PyTorch only owns memory, the autograd graph edges between
+the coarse ops and the process group.  No CPU / eager fallback: without the HIP library every
+compute call raises.
+
+Memory layout (MI355X-first): all fp32 master parameters live in ONE flat HBM buffer and all
+gradients in another (``nn.Parameter``s are views), so the optimiser is two launches and the
+data-parallel gradient exchange is one bucket per tower; bf16 GEMM operand copies (straight
+and transposed) are refreshed from the masters when their version counters move.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from ctypes import c_float, c_int, c_long, c_void_p
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream
+from .utils_image import patch_from_norm_bbox
+
+
+# --------------------------------------------------------------------------- ctypes structs
+
+class _BlockParams(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "ln1_w", "ln1_b", "ln2_w", "ln2_b", "b_qkv", "b_out", "b_fc", "b_proj",
+        "w_qkv", "w_out", "w_fc", "w_proj", "wt_qkv", "wt_out", "wt_fc", "wt_proj",
+        "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b", "g_b_qkv", "g_b_out", "g_b_fc", "g_b_proj",
+        "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj")]
+
+
+class _TowerDesc(ctypes.Structure):
+    _fields_ = [("layers", c_int), ("width", c_int), ("heads", c_int), ("tokens", c_int), ("causal", c_int),
+                ("blocks", ctypes.POINTER(_BlockParams))]
+
+
+# --------------------------------------------------------------------------- parameter holders
+# Plain containers that reproduce the reference's module tree so that state_dict() yields the
+# same keys in the same order (model_clip.py:171-183, :214-230, :317-330).
+
+class _Affine(nn.Module):
+    def __init__(self, d: int, bias_init: float = 0.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _Linear(nn.Module):
+    def __init__(self, d_in: int, d_out: int):
+        super().__init__()
+        bound = 1.0 / math.sqrt(d_in)
+        self.weight = nn.Parameter(torch.empty(d_out, d_in).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(d_out).uniform_(-bound, bound))
+
+
+class _MHAParams(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _Linear(d, d)
+        with torch.no_grad():
+            self.out_proj.bias.zero_()
+
+
+class _MLP(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.c_fc = _Linear(d, 4 * d)
+        self.c_proj = _Linear(4 * d, d)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model: int, n_head: int):
+        super().__init__()
+        self.attn = _MHAParams(d_model)
+        self.ln_1 = _Affine(d_model)
+        self.mlp = _MLP(d_model)
+        self.ln_2 = _Affine(d_model)
+        self.n_head = n_head
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class _Conv1(nn.Module):
+    def __init__(self, width: int, patch: int):
+        super().__init__()
+        fan_in = 3 * patch * patch
+        bound = 1.0 / math.sqrt(fan_in)
+        self.weight = nn.Parameter(torch.empty(width, 3, patch, patch).uniform_(-bound, bound))
+
+
+class VisualTransformer(nn.Module):
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int):
+        super().__init__()
+        self.input_resolution, self.output_dim, self.patch_size = input_resolution, output_dim, patch_size
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.patch_num = input_resolution // patch_size
+        self.positional_embedding = nn.Parameter(scale * torch.randn(self.patch_num ** 2 + 1, width))
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self.conv1 = _Conv1(width, patch_size)
+        self.ln_pre = _Affine(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = _Affine(width)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, vocab: int, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(vocab, d))
+
+
+# --------------------------------------------------------------------------- workspace pool
+
+class _Pool:
+    """Reusable device buffers keyed by (tag, bytes); a buffer is busy from a forward until the
+    matching backward (or until the autograd context is dropped)."""
+
+    def __init__(self):
+        self.free: Dict[Tuple, List[torch.Tensor]] = {}
+
+    def take(self, tag, nbytes: int, device) -> torch.Tensor:
+        key = (tag, nbytes, str(device))
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def give(self, tag, buf: torch.Tensor):
+        self.free.setdefault((tag, buf.numel(), str(buf.device)), []).append(buf)
+
+
+class _Lease:
+    """Returns its buffer to the pool when garbage-collected (ctx freed) or released."""
+
+    def __init__(self, pool: _Pool, tag, buf):
+        self.pool, self.tag, self.buf = pool, tag, buf
+
+    def release(self):
+        if self.buf is not None:
+            self.pool.give(self.tag, self.buf)
+            self.buf = None
+
+    def __del__(self):
+        self.release()
+
+
+# --------------------------------------------------------------------------- the model
+
+_GEMM_SUFFIXES = ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")
+
+
+class CLIP(nn.Module):
+    """``CLIP`` of model_clip.py:266-552 (ViT vision tower)."""
+
+    def __init__(self, embed_dim: int, image_resolution: int, vision_layers: int, vision_width: int,
+                 vision_patch_size: int, context_length: int, vocab_size: int, transformer_width: int,
+                 transformer_heads: int, transformer_layers: int, constrastive_overbatch=True, alignment=False,
+                 multiattention=False):
+        super().__init__()
+        if isinstance(vision_layers, (tuple, list)):
+            raise NotImplementedError("ModifiedResNet towers are out of scope (BASELINE.json names ViT only)")
+        self.context_length = context_length
+        self.vision_width = vision_width
+        self.embed_dim = embed_dim
+        vision_heads = vision_width // 64
+        self.visual = VisualTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
+                                        vision_heads, embed_dim)
+        self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads)
+        self.vocab_size = vocab_size
+        self.token_embedding = _Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = _Affine(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.initialize_parameters()
+        self.constrastive_overbatch = constrastive_overbatch
+        self.alignment = alignment
+        self.multiattention = multiattention      # stored, never read: as in the reference
+        from .losses import cross_entropy
+        self.loss_func = cross_entropy            # the reference forgets to define it
+        # device state (built lazily on the first forward on a GPU)
+        self._flat: Optional[torch.Tensor] = None
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._pool = _Pool()
+        self._trigger = None
+        self._versions = None
+        self.grad_sync = None                     # optional callable(model, tower_name) for DP overlap
+
+    # ---- reference API -------------------------------------------------------------------
+    def set_hyps(self, constrastive_overbatch=True, alignment=False, multiattention=False):
+        self.constrastive_overbatch = constrastive_overbatch
+        self.alignment = alignment
+        self.multiattention = multiattention
+
+    def initialize_parameters(self):
+        """model_clip.py:348-375 (text tower only; the vision tower keeps its constructor init)."""
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        w, layers = self.transformer.width, self.transformer.layers
+        proj_std = (w ** -0.5) * ((2 * layers) ** -0.5)
+        attn_std = w ** -0.5
+        fc_std = (2 * w) ** -0.5
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=w ** -0.5)
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    # ---- flat parameter / gradient buffers ---------------------------------------------------
+    def _flat_ok(self) -> bool:
+        if self._flat is None:
+            return False
+        p = self.positional_embedding
+        return p.device == self._flat.device and p.data_ptr() == self._flat.data_ptr() + self._offsets["positional_embedding"] * 4
+
+    def _prepare(self):
+        """Move every parameter into one flat fp32 buffer (views keep the reference's names)."""
+        dev = self.positional_embedding.device
+        if dev.type != "cuda":
+            raise L.HipExtensionMissing("clip_event_amd computes on an AMD GPU only; move the model with .cuda() first")
+        lib()
+        named = list(self.named_parameters())
+        offsets, off = {}, 0
+        # contiguous ranges per tower so that each tower's gradients form one communication bucket
+        order = ([n for n, _ in named if not n.startswith("visual.") and not n.startswith("transformer.")]
+                 + [n for n, _ in named if n.startswith("visual.")]
+                 + [n for n, _ in named if n.startswith("transformer.")])
+        pmap = dict(named)
+        ranges = {}
+        for group, pred in (("head", lambda n: not n.startswith(("visual.", "transformer."))),
+                            ("visual", lambda n: n.startswith("visual.")),
+                            ("text", lambda n: n.startswith("transformer."))):
+            start = off
+            for n in order:
+                if pred(n):
+                    offsets[n] = off
+                    off += (pmap[n].numel() + 63) // 64 * 64
+            ranges[group] = (start, off)
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for n, p in named:
+                if p.dtype != torch.float32:
+                    raise RuntimeError(f"parameter {n} is {p.dtype}; master weights are fp32")
+                view = flat[offsets[n]: offsets[n] + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = None
+        self._flat, self._flat_grad, self._offsets, self._ranges = flat, flat_grad, offsets, ranges
+        self._pmap = pmap
+        self._trigger = torch.zeros(1, device=dev, requires_grad=True)
+        self._build_device_tables()
+        self._versions = None
+
+    def _gview(self, name: str) -> torch.Tensor:
+        p = self._pmap[name]
+        o = self._offsets[name]
+        return self._flat_grad[o: o + p.numel()].view(p.shape)
+
+    def _attach_grads(self):
+        """Point every ``p.grad`` at its slice of the flat gradient buffer.  A slice whose
+        ``p.grad`` was None (``zero_grad(set_to_none=True)``) is zero-filled first; a foreign
+        ``p.grad`` tensor (autograd accumulated into a parameter before our backward ran, e.g.
+        ``logit_scale``) is copied into its slice."""
+        base = self._flat_grad.data_ptr()
+        todo = [(n, p) for n, p in self._pmap.items() if p.grad is None or p.grad.data_ptr() != base + self._offsets[n] * 4]
+        if not todo:
+            return
+        if all(p.grad is None for _, p in todo) and len(todo) == len(self._pmap):
+            self._flat_grad.zero_()
+            for n, p in todo:
+                p.grad = self._gview(n)
+            return
+        for n, p in todo:
+            view = self._gview(n)
+            if p.grad is None:
+                view.zero_()
+            else:
+                view.copy_(p.grad)
+            p.grad = view
+
+    def zero_grad(self, set_to_none: bool = False):  # noqa: D401 - nn.Module API
+        if self._flat_grad is not None and not set_to_none:
+            self._flat_grad.zero_()
+            self._attach_grads_fast()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    def _attach_grads_fast(self):
+        for n, p in self._pmap.items():
+            if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + self._offsets[n] * 4:
+                p.grad = self._gview(n)
+
+    # ---- bf16 operand copies + tower descriptors -------------------------------------------
+    def _build_device_tables(self):
+        dev = self._flat.device
+        self._w16: Dict[str, torch.Tensor] = {}
+        self._w16t: Dict[str, torch.Tensor] = {}
+        gemm_names = [n for n in self._pmap if n.endswith(_GEMM_SUFFIXES)]
+        for n in gemm_names:
+            p = self._pmap[n]
+            self._w16[n] = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)
+            self._w16t[n] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=dev)
+        v = self.visual
+        kp = 3 * v.patch_size * v.patch_size
+        if kp % 8 != 0:
+            raise NotImplementedError(f"patch size {v.patch_size}: 3*p*p must be a multiple of 8 for the bf16 patch GEMM")
+        self._kp = kp
+        self._w16["visual.conv1.weight"] = torch.empty(self.vision_width, kp, dtype=torch.bfloat16, device=dev)
+        for n in ("visual.proj", "text_projection"):
+            p = self._pmap[n]
+            self._w16[n] = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)                 # [width, E]
+            self._w16t[n] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=dev)  # [E, width]
+        self._cast_list = gemm_names + ["visual.conv1.weight", "visual.proj", "text_projection"]
+
+        def desc(prefix: str, tr: Transformer, tokens: int, causal: bool):
+            arr = (_BlockParams * tr.layers)()
+            for i in range(tr.layers):
+                b = f"{prefix}resblocks.{i}."
+                f = arr[i]
+
+                def P(name):
+                    return self._pmap[b + name].data_ptr()
+
+                def G(name):
+                    return self._gview(b + name).data_ptr()
+
+                f.ln1_w, f.ln1_b, f.ln2_w, f.ln2_b = P("ln_1.weight"), P("ln_1.bias"), P("ln_2.weight"), P("ln_2.bias")
+                f.b_qkv, f.b_out = P("attn.in_proj_bias"), P("attn.out_proj.bias")
+                f.b_fc, f.b_proj = P("mlp.c_fc.bias"), P("mlp.c_proj.bias")
+                for short, name in (("qkv", "attn.in_proj_weight"), ("out", "attn.out_proj.weight"),
+                                    ("fc", "mlp.c_fc.weight"), ("proj", "mlp.c_proj.weight")):
+                    setattr(f, "w_" + short, self._w16[b + name].data_ptr())
+                    setattr(f, "wt_" + short, self._w16t[b + name].data_ptr())
+                    setattr(f, "g_w_" + short, G(name))
+                f.g_ln1_w, f.g_ln1_b, f.g_ln2_w, f.g_ln2_b = G("ln_1.weight"), G("ln_1.bias"), G("ln_2.weight"), G("ln_2.bias")
+                f.g_b_qkv, f.g_b_out = G("attn.in_proj_bias"), G("attn.out_proj.bias")
+                f.g_b_fc, f.g_b_proj = G("mlp.c_fc.bias"), G("mlp.c_proj.bias")
+            d = _TowerDesc(tr.layers, tr.width, tr.heads, tokens, 1 if causal else 0, arr)
+            d._keep = arr
+            return d
+
+        self._vdesc = desc("visual.transformer.", self.visual.transformer, self.visual.patch_num ** 2 + 1, False)
+        self._tdesc = desc("transformer.", self.transformer, self.context_length, True)
+        lib().ce_tower_workspace_bytes.restype = ctypes.c_size_t
+
+    def refresh_operands(self, force: bool = False):
+        """Re-cast the bf16 GEMM operands from the fp32 masters when a master changed
+        (in-place optimiser update, ``load_state_dict``)."""
+        vers = tuple(self._pmap[n]._version for n in self._cast_list)
+        if not force and vers == self._versions:
+            return
+        s = stream()
+        cl = lib()
+        for n in self._cast_list:
+            p = self._pmap[n]
+            if n == "visual.conv1.weight":
+                check(cl.ce_cast_bf16(ptr(p), ptr(self._w16[n]), c_long(p.numel()), s), "ce_cast_bf16")
+            else:
+                w16, w16t = self._w16[n], self._w16t[n]
+                check(cl.ce_cast_transpose(ptr(p), ptr(w16), c_long(w16.stride(0)), ptr(w16t), c_long(w16t.stride(0)),
+                                           c_int(p.shape[0]), c_int(p.shape[1]), s), "ce_cast_transpose")
+        self._versions = vers
+
+    def mark_operands_stale(self):
+        self._versions = None
+
+    def _ready(self):
+        if not self._flat_ok():
+            self._prepare()
+        self.refresh_operands()
+
+    # ---- encoders -------------------------------------------------------------------------
+    def encode_image(self, image, use_grid: bool = False):
+        """model_clip.py:390-391 -> VisualTransformer.forward (:232-263)."""
+        self._ready()
+        from .functional import EncodeImageFn
+        return EncodeImageFn.apply(image, self._trigger, self, bool(use_grid))
+
+    def encode_text(self, text):
+        """model_clip.py:398-417."""
+        self._ready()
+        from .functional import EncodeTextFn
+        return EncodeTextFn.apply(text, self._trigger, self)
+
+    def forward(self, image, text, train_arg=None, bboxs=None, bbox_desc_vec=None, bbox_label_vec=None):
+        """model_clip.py:419-528."""
+        from .functional import logits_from_features
+        image_features = self.encode_image(image, use_grid=train_arg is not None)
+        if train_arg is not None:
+            from .region import region_losses
+            B = image_features.size(0)
+            pn = self.visual.patch_num
+            grid_features = image_features[:, 1:, :].reshape(B, pn, pn, -1)
+            image_features = image_features[:, 0, :]
+            loss_per_bbox, loss_per_arg = region_losses(self, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg)
+        text_features = self.encode_text(text)
+        logits_per_image, logits_per_text = logits_from_features(
+            image_features, text_features, self.logit_scale, self.constrastive_overbatch)
+        if train_arg is not None:
+            return logits_per_image, logits_per_text, loss_per_bbox, loss_per_arg
+        return logits_per_image, logits_per_text
+
+    def sim_entity(self, img_obj, txt_ent):
+        """model_clip.py:531-552: un-normalised object / entity features."""
+        B, n_img, n_txt = img_obj.size(0), img_obj.size(1), txt_ent.size(1)
+        image_features = self.encode_image(img_obj.reshape(B * n_img, img_obj.size(2), img_obj.size(3), img_obj.size(4)))
+        image_features = image_features.view(B, n_img, -1)
+        text_features = self.encode_text(txt_ent.reshape(B * n_txt, txt_ent.size(2)))
+        text_features = text_features.view(B, n_txt, -1)
+        return image_features, text_features
+
+
+def build_model(state_dict: dict) -> CLIP:
+    """model_clip.py:578-617 (ViT branch): hyper-parameters inferred from tensor shapes, strict load,
+    returned in train mode."""
+    if "visual.proj" not in state_dict:
+        raise NotImplementedError("ModifiedResNet checkpoints are out of scope (ViT towers only)")
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict.keys() if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    image_resolution = vision_patch_size * grid_size
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    transformer_width = state_dict["ln_final.weight"].shape[0]
+    transformer_heads = transformer_width // 64
+    transformer_layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size,
+                 context_length, vocab_size, transformer_width, transformer_heads, transformer_layers)
+    for key in ["input_resolution", "context_length", "vocab_size"]:
+        if key in state_dict:
+            del state_dict[key]
+    model.load_state_dict(state_dict)
+    return model

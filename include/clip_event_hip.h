@@ -21,6 +21,7 @@
 #ifndef CLIP_EVENT_HIP_H
 #define CLIP_EVENT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -73,6 +74,88 @@ int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, in
                      void* stream);
 int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
                      const float* lse, void* dqkv, long lddq, int B, int L, int H, int causal, void* stream);
+
+/* ---- input side, bookkeeping (embed.hip) ---- */
+/* image f32 [B,3,R,R] -> patch rows bf16 [B*(R/p)^2, k_padded], columns ordered (c, py, px) like the
+ * flattened conv1.weight; columns >= 3*p*p are zero.  Conv2d(k=s=p), model_clip.py:219,235. */
+int ce_im2col(const float* image, void* patches, int B, int resolution, int patch, int k_padded, void* stream);
+/* x0[b,t,:] = (t==0 ? class_embedding : patch_out[b*(T-1)+t-1,:]) + positional_embedding[t,:]
+ * (model_clip.py:237-242); the backward emits the bf16 patch-row gradient for the conv wgrad. */
+int ce_vision_assemble(const float* patch_out, const float* cls, const float* pos, float* x0, int B, int tokens,
+                       int D, void* stream);
+int ce_vision_assemble_bwd(const float* dx0, void* dpatch, int B, int tokens, int D, void* stream);
+/* x0[r,:] = token_embedding[ids[r],:] + positional_embedding[r % tokens,:]  (model_clip.py:400-403) */
+int ce_token_embed(const int64_t* ids, const float* table, const float* pos, float* x0, long rows, int tokens,
+                   int D, int vocab, void* stream);
+int ce_token_embed_bwd(const int64_t* ids, const float* dx0, float* dtable, long rows, int D, int vocab,
+                       void* stream);
+/* out[i] (+)= sum_b x[b*slab + i], i < n  (positional / class embedding gradients) */
+int ce_batch_reduce(const float* x, float* out, int B, long slab, long n, int accumulate, void* stream);
+/* out[n] += sum_m x[m,n]  (bias gradients; atomics) */
+int ce_colsum_bf16(const void* x, long ld, float* out, int M, int N, void* stream);
+/* fp32 master weight [R,C] -> bf16 copy [R,C] (nullable) and bf16 transposed copy [C,R] (nullable) */
+int ce_cast_transpose(const float* w, void* w16, long ld16, void* w16t, long ld16t, int R, int C, void* stream);
+int ce_cast_bf16(const float* x, void* y, long n, void* stream);
+/* rows[r] = r*tokens + argmax_t ids[r,t]  (EOT gather index, model_clip.py:415; first maximum) */
+int ce_eot_rows(const int64_t* ids, int* rows, long n, int tokens, void* stream);
+
+/* ---- contrastive head (head.hip) ---- */
+int ce_l2norm_fwd(const float* f, long ldf, float* y, long ldy, float* inv_norm, int n, int E, void* stream);
+int ce_l2norm_bwd(const float* dy, long lddy, const float* y, long ldy, const float* inv_norm, float* df, long lddf,
+                  int n, int E, int accumulate, void* stream);
+/* C[m,n] = alpha' * sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn] + beta*C; alpha' = alpha * (alpha_ptr ?
+ * (alpha_exp ? exp(*alpha_ptr) : *alpha_ptr) : 1).  fp32; logits and their gradients. */
+int ce_sgemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M,
+             int N, int K, const float* alpha_ptr, float alpha, int alpha_exp, float beta, void* stream);
+/* mean cross-entropy over the selected rows (sel = index_pos or NULL): *loss += mean(lse - logit[label]) */
+int ce_xent_fwd(const float* logits, long ld, const int64_t* labels, const int64_t* sel, float* row_lse,
+                float* loss, int nrows, int C, void* stream);
+int ce_xent_bwd(const float* logits, long ld, const int64_t* labels, const int64_t* sel, const float* row_lse,
+                const float* grad, float* dlogits, long ldd, int nrows, int C, void* stream);
+int ce_dot(const float* a, const float* b, long n, float* out, void* stream);
+/* per-instance logits_per_image (model_clip.py:509-521): lpi[b,k] = exp(*logit_scale) <In[b], Tn[b*K+k]> */
+int ce_instance_logits(const float* In, const float* Tn, const float* logit_scale, float* lpi, int B, int K, int E,
+                       void* stream);
+int ce_instance_logits_bwd(const float* dlpi, const float* In, const float* Tn, const float* logit_scale, float* dIn,
+                           float* dTn, int B, int K, int E, void* stream);
+/* mean-reduced elementwise losses: mode 0 = BCEWithLogits, mode 1 = KLDiv (model_clip.py:626-629) */
+int ce_elem_loss_fwd(const float* x, const float* y, long n, int mode, float* loss, void* stream);
+int ce_elem_loss_bwd(const float* x, const float* y, long n, int mode, const float* grad, float* dx, void* stream);
+
+/* ---- optimiser (optim.hip): clip_grad_norm_(.,max_norm) + Adam(L2 weight decay), engine.py:89-90 ---- */
+int ce_sumsq(const float* g, long n, float* out, void* stream);
+int ce_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float max_norm, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* ---- transformer tower runner (tower.cpp): the 12x ResidualAttentionBlock loop of
+ * Transformer.forward (model_clip.py:171-211) and its backward, all launches issued from C++ ---- */
+typedef struct ce_block_params {
+    /* fp32 master parameters (reference state-dict tensors, model_clip.py:175-182) */
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const float *b_qkv, *b_out, *b_fc, *b_proj;
+    /* bf16 GEMM operands: w_* = [out,in] as stored by the reference, wt_* = [in,out] transposed copy */
+    const void *w_qkv, *w_out, *w_fc, *w_proj;
+    const void *wt_qkv, *wt_out, *wt_fc, *wt_proj;
+    /* fp32 gradients, accumulated (+=) */
+    float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b;
+    float *g_b_qkv, *g_b_out, *g_b_fc, *g_b_proj;
+    float *g_w_qkv, *g_w_out, *g_w_fc, *g_w_proj;
+} ce_block_params;
+
+typedef struct ce_tower_desc {
+    int layers, width, heads, tokens, causal;
+    const ce_block_params* blocks; /* host array [layers] of device pointers */
+} ce_tower_desc;
+
+/* bytes of activation stash + backward scratch for `batch` samples */
+size_t ce_tower_workspace_bytes(const ce_tower_desc* d, int batch);
+/* x_out[B*T, width] (f32) = blocks(x0[B*T, width] (f32)); stash kept in `workspace` for the backward;
+ * x0 must stay valid until ce_tower_backward has run. */
+int ce_tower_forward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* x_out,
+                     void* stream);
+/* dx (f32 [B*T, width]): in = gradient w.r.t. x_out, out = gradient w.r.t. x0 (in place);
+ * parameter gradients are accumulated into the g_* buffers. */
+int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx, void* stream);
 
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);

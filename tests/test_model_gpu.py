@@ -1,0 +1,175 @@
+"""GPU parity of the drop-in model (HIP path through the C ABI) against the CPU oracle and the
+goldens captured from the reference.  The HIP path computes GEMMs on bf16 operands with fp32
+accumulation; the stated tolerances are bf16-level against the fp32 reference and tighter
+against the oracle run with the same bf16 rounding points (``bf16=True``)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _mk(cfg, seed):
+    from oracle import clip_oracle as O
+    from clip_event_amd.model import build_model
+    sd = O.init_params(cfg, seed)
+    m = build_model({k: v.clone() for k, v in sd.items()}).to(DEV)
+    return m, sd
+
+
+def _cos(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _grad_report(model, ref_grads, tag):
+    worst = (1.0, None)
+    rels = []
+    for n, p in model.named_parameters():
+        g = ref_grads[n]
+        if g is None or float(g.norm()) == 0.0:
+            continue
+        c = _cos(p.grad, g)
+        rels.append(_rel(p.grad, g))
+        if c < worst[0]:
+            worst = (c, n)
+    print(f"[{tag}] worst grad cosine {worst[0]:.5f} at {worst[1]}; median rel-l2 {np.median(rels):.4f} max {max(rels):.4f}")
+    return worst, rels
+
+
+@pytest.mark.parametrize("overbatch", [True, False])
+def test_tiny_against_oracle(overbatch):
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    from tests.util import golden_json
+    G = golden_json()["tiny"]
+    cfg = O.ClipConfig(**G["cfg"])
+    m, sd = _mk(cfg, G["param_seed"])
+    m.set_hyps(constrastive_overbatch=overbatch)
+    B, K = G["B"], G["K"]
+    img = S.synthetic_images(B, cfg.image_resolution, seed=G["img_seed"])
+    txt = S.synthetic_tokens(B * K, cfg.context_length, cfg.vocab_size, seed=G["txt_seed"], min_len=G["txt_min_len"])
+    yi, yt, ip = O.build_labels(B, 1, K - 1, overbatch)
+    # oracle, fp32 and bf16-emulated
+    ld32, g32, (li32, lt32) = O.loss_and_grads(sd, cfg, img, txt, yi, yt, ip, overbatch)
+    li16, lt16 = O.clip_forward(sd, cfg, img, txt, overbatch, bf16=True)
+    # HIP
+    li, lt = m(img.to(DEV), txt.to(DEV))
+    crit = CriterionContrastive("ce")
+    ld = crit(li, lt, yi.to(DEV), yt.to(DEV), index_pos=ip.to(DEV), constrastive_overbatch=overbatch)
+    (ld["loss_i"] + ld["loss_t"]).backward()
+    torch.cuda.synchronize()
+    print(f"logits_per_image: vs fp32 max|d|={float((li.cpu()-li32).abs().max()):.4f}  vs bf16-oracle max|d|={float((li.cpu()-li16).abs().max()):.4f}")
+    print(f"loss_i {float(ld['loss_i']):.5f} (ref {float(ld32['loss_i']):.5f})  loss_t {float(ld['loss_t']):.5f} (ref {float(ld32['loss_t']):.5f})")
+    assert (li.cpu() - li16).abs().max() < 0.05 and (lt.cpu() - lt16).abs().max() < 0.05       # same rounding points
+    assert (li.cpu() - li32).abs().max() < 0.15 and (lt.cpu() - lt32).abs().max() < 0.15       # bf16 vs fp32, logits ~ +-14
+    assert abs(float(ld["loss_i"]) - float(ld32["loss_i"])) < 2e-2
+    assert abs(float(ld["loss_t"]) - float(ld32["loss_t"])) < 2e-2
+    worst, rels = _grad_report(m, g32, f"tiny overbatch={overbatch}")
+    assert worst[0] > 0.98 and np.median(rels) < 0.03
+
+
+def test_tiny_features_bf16_oracle():
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from tests.util import golden_json
+    G = golden_json()["tiny"]
+    cfg = O.ClipConfig(**G["cfg"])
+    m, sd = _mk(cfg, G["param_seed"])
+    img = S.synthetic_images(G["B"], cfg.image_resolution, seed=G["img_seed"])
+    txt = S.synthetic_tokens(G["B"] * G["K"], cfg.context_length, cfg.vocab_size, seed=G["txt_seed"], min_len=G["txt_min_len"])
+    with torch.no_grad():
+        fi = m.encode_image(img.to(DEV)).cpu()
+        fg = m.encode_image(img.to(DEV), use_grid=True).cpu()
+        ft = m.encode_text(txt.to(DEV)).cpu()
+    for name, got, ref16, ref32 in (
+            ("image", fi, O.encode_image(sd, cfg, img, bf16=True), O.encode_image(sd, cfg, img)),
+            ("grid", fg, O.encode_image(sd, cfg, img, use_grid=True, bf16=True), O.encode_image(sd, cfg, img, use_grid=True)),
+            ("text", ft, O.encode_text(sd, cfg, txt, bf16=True), O.encode_text(sd, cfg, txt))):
+        print(f"[{name}] rel-l2 vs bf16-oracle {_rel(got, ref16):.2e}, vs fp32 {_rel(got, ref32):.2e}, cos {_cos(got, ref32):.6f}")
+        assert _rel(got, ref16) < 5e-3 and _cos(got, ref32) > 0.9995
+    assert tuple(fg.shape) == (G["B"], cfg.vision_tokens, cfg.embed_dim)
+
+
+def test_vitb32_b8_against_reference_golden():
+    """BASELINE config 1 on the GPU: ViT-B/32, batch 8, caption-only InfoNCE, vs the imported reference."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    from tests.util import golden_json, golden_npz, summary_of
+    G = golden_json()["vitb32"]
+    Z = golden_npz("vitb32_b8.npz")
+    m, sd = _mk(O.VIT_B32, G["param_seed"])
+    img = S.synthetic_images(8, 224, seed=G["img_seed"]).to(DEV)
+    txt = torch.from_numpy(Z["tokens"]).to(DEV)
+    li, lt = m(img, txt)
+    y = torch.arange(8, device=DEV)
+    ld = CriterionContrastive("ce")(li, lt, y, y, index_pos=y)
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    dli = float((li.detach().cpu() - torch.from_numpy(Z["logits_per_image"])).abs().max())
+    print(f"ViT-B/32 B=8: max|dlogit|={dli:.4f} loss_i {float(ld['loss_i']):.5f} (ref {G['loss_i']:.5f}) loss_t {float(ld['loss_t']):.5f} (ref {G['loss_t']:.5f})")
+    assert dli < 0.2
+    assert abs(float(ld["loss_i"]) - G["loss_i"]) < 2e-2 and abs(float(ld["loss_t"]) - G["loss_t"]) < 2e-2
+    with torch.no_grad():
+        fi = m.encode_image(img).cpu()
+        ft = m.encode_text(txt).cpu()
+    assert _cos(fi, torch.from_numpy(Z["image_features"])) > 0.999
+    assert _cos(ft, torch.from_numpy(Z["text_features"])) > 0.999
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    print(f"grad norm {gn:.4f} (ref {G['grad_norm']:.4f})")
+    assert abs(gn - G["grad_norm"]) < 0.05 * G["grad_norm"]
+    bad = []
+    for n, p in m.named_parameters():
+        gs = G["grads"][n]
+        norm, _, vals = summary_of(p.grad, gs["idx"])
+        if abs(norm - gs["norm"]) > 0.08 * gs["norm"] + 1e-7:
+            bad.append((n, norm, gs["norm"]))
+    print("params with >8% grad-norm deviation:", bad[:10])
+    assert not bad
+
+
+def test_train_step_fused_adam():
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    from clip_event_amd.optim import FusedAdam
+    from tests.util import golden_json
+    G = golden_json()
+    cfg = O.ClipConfig(**G["tiny"]["cfg"])
+    m, sd = _mk(cfg, 11)
+    img = S.synthetic_images(4, cfg.image_resolution, seed=31)
+    txt = S.synthetic_tokens(4, cfg.context_length, cfg.vocab_size, seed=32, min_len=2)
+    yi, yt, ip = O.build_labels(4, 1, 0, True)
+    opt = FusedAdam(m, lr=G["tiny_step"]["lr"], weight_decay=G["tiny_step"]["weight_decay"], max_norm=1.0)
+    crit = CriterionContrastive("ce")
+    p_ref, state = sd, {}
+    for step in G["tiny_step"]["steps"]:
+        li, lt = m(img.to(DEV), txt.to(DEV))
+        ld = crit(li, lt, yi.to(DEV), yt.to(DEV), index_pos=ip.to(DEV))
+        opt.zero_grad()
+        sum(ld.values()).backward()
+        opt.step()
+        torch.cuda.synchronize()
+        p_ref, ld_ref, gn_ref = O.train_step(p_ref, cfg, state, img, txt, yi, yt, ip, lr=G["tiny_step"]["lr"],
+                                             weight_decay=G["tiny_step"]["weight_decay"])
+        print(f"step loss_i {float(ld['loss_i']):.5f} (ref {step['loss_i']:.5f}) grad_norm {float(opt.grad_norm()):.4f} (ref {step['grad_norm']:.4f})")
+        assert abs(float(ld["loss_i"]) - step["loss_i"]) < 3e-2
+        assert abs(float(opt.grad_norm()) - step["grad_norm"]) < 0.05 * step["grad_norm"]
+    # Adam normalises the update to ~lr per element: compare the parameter DELTAS direction
+    worst = 1.0
+    for n, p in m.named_parameters():
+        d_hip = p.detach().cpu() - sd[n]
+        d_ref = p_ref[n] - sd[n]
+        if float(d_ref.norm()) > 0:
+            worst = min(worst, _cos(d_hip, d_ref))
+    print("worst parameter-delta cosine after 2 Adam steps:", worst)
+    assert worst > 0.9
