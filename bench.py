@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLIP-Event contrastive TRAIN STEP on MI355X (BASELINE.json configs[1]).
+
+One step = forward (ViT-B/32 image tower + 77-token text tower) + global-batch InfoNCE +
+backward + clip_grad_norm_(.,1) + Adam, on synthetic 224px images / 77-token captions with
+random-init weights, per-GPU batch 256, bf16 GEMM operands (fp32 accumulate / residual / master).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+`roofline` (dominant kernel class, algorithmic FLOPs / HIP-event time measured in an instrumented
+pass of the same step) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 44.10e9        # ViT-B/32 fwd+bwd, K=1, no patch-conv dgrad
+PEAK_BF16 = 2.5e15             # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU image batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """Threads this process may really use: affinity mask, capped by the cgroup CPU quota and by 16
+    (the GPU box's CPU share per GPU); oversubscribing the host makes the CPU oracle crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline():
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference) on this host's cores:
+    config c1 exactly (ViT-B/32, B=8, caption-only InfoNCE, full step with clip + Adam)."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
+    p = O.init_params(O.VIT_B32, 0)
+    B = 8
+    img = S.synthetic_images(B, 224, seed=999)
+    txt = S.synthetic_tokens(B, 77, 49408, seed=999)
+    y = torch.arange(B)
+    state = {}
+    t0 = time.time()
+    p, _, _ = O.train_step(p, O.VIT_B32, state, img, txt, y, y, y)     # warm-up
+    warm = time.time() - t0
+    log(f"cpu baseline warm-up step {warm:.1f}s")
+    n, t0 = 0, time.time()
+    budget = 20.0
+    while n < 2 or (time.time() - t0 < budget and n < 8):
+        p, _, _ = O.train_step(p, O.VIT_B32, state, img, txt, y, y, y)
+        n += 1
+        log(f"cpu baseline step {n}: {(time.time() - t0) / n:.2f}s/step")
+        if warm > 30 and n >= 1:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full train steps of ViT-B/32 at batch {B} (BASELINE config 1), fp32, CPU oracle"}
+
+
+def ms_per_step_tmp(dt, steps):
+    return dt / steps * 1e3
+
+
+def main():
+    args = parse()
+    W = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if W > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" == RCCL on ROCm
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from oracle import clip_oracle as O              # only for the synthetic state dict + CPU baseline
+    from clip_event_amd import synthetic as S
+    from clip_event_amd import distributed as D
+    from clip_event_amd._lib import lib
+    from clip_event_amd.engine import train_step
+    from clip_event_amd.losses import CriterionContrastive
+    from clip_event_amd.model import build_model
+    from clip_event_amd.optim import FusedAdam
+
+    B = args.batch
+    model = build_model(O.init_params(O.VIT_B32, 0)).to(dev)       # same weights on every rank
+    crit = CriterionContrastive("ce")
+    opt = FusedAdam(model, lr=1e-6, weight_decay=0.0, max_norm=1.0)    # README.md:189-191 defaults
+    sync = D.GradSync(model) if W > 1 else None
+    img = S.synthetic_images(B, 224, seed=999 + rank).to(dev)
+    txt = S.synthetic_tokens(B, 77, 49408, seed=999 + rank).to(dev)
+    yi, yt, ip = D.global_labels(B, 1, 0, True, device=dev, rank_=rank)
+
+    def step():
+        return train_step(model, crit, opt, img, txt, yi, yt, ip, grad_sync=sync)
+
+    for _ in range(args.warmup):
+        ld = step()
+    if W > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld = step()
+    torch.cuda.synchronize()
+    if W > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if W > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(sum(v.detach() for v in ld.values()))
+    log(f"timed region: {ms_per_step_tmp(dt, args.steps):.2f} ms/step")
+    ms_per_step = dt / args.steps * 1e3
+    pairs_per_s = B * W * args.steps / dt
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass: HIP events on the launch stream around every launch, summed per kernel class
+        cl = lib()
+        cl.ce_profile_class_name.restype = ctypes.c_char_p
+        cl.ce_profile_enable(1)
+        n_prof = 2
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+        ncls = 14
+        buf = (ctypes.c_double * (ncls * 4))()
+        cl.ce_profile_collect(buf, ncls)
+        cl.ce_profile_enable(0)
+        log("instrumented pass collected")
+        rows = []
+        for c in range(ncls):
+            cnt, ms, fl, by = buf[c * 4:(c + 1) * 4]
+            if cnt > 0:
+                rows.append({"kernel": cl.ce_profile_class_name(c).decode(), "launches_per_step": cnt / n_prof,
+                             "ms_per_step": ms / n_prof, "avg_us": ms / cnt * 1e3,
+                             "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                             "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        top = rows[0]
+        mfma = top["kernel"].startswith("gemm") or top["kernel"].startswith("attn")
+        ach = top["tflops"] if mfma else top["gbps"]
+        peak = PEAK_BF16 / 1e12 if mfma else PEAK_HBM / 1e9
+        roof = {"bound": "mfma" if mfma else "hbm", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
+                "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
+                "step_frac_of_bf16_peak": round(pairs_per_s / W * FLOP_PER_PAIR / PEAK_BF16, 4),
+                "classes": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+    if W > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and W == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "image-text pairs/sec/GPU, ViT-B/32 224px x 77-tok, global-batch contrastive",
+            "value": round(pairs_per_s, 2), "unit": "pairs/s (whole job)", "per_gpu": round(pairs_per_s / W, 2),
+            "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=1, InfoNCE only, full train step "
+                                   "(fwd+bwd+clip_grad_norm+Adam), random-init weights" % B,
+                       "global_batch": B * W, "parallelism": "dp%d" % W, "loss": round(loss, 4)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if W > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -304,6 +304,7 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
     const size_t lds = 2 * (size_t)Lp * ROW;
     const float scale = 0.125f;  // 1/sqrt(64)
     hipStream_t s = (hipStream_t)stream;
+    CeProfScope prof(CE_PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (4.0 * D), s);
 #define CALL(TT)                                                                                              \
     hipLaunchKernelGGL(attn_fwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, \
                        lse, L, H, D, causal, scale)
@@ -326,6 +327,7 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
     const size_t lds = 4 * (size_t)Lp * ROW + 2 * (size_t)Lp * (Lp * 2 + 32);
     const float scale = 0.125f;
     hipStream_t s = (hipStream_t)stream;
+    CeProfScope prof(CE_PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (8.0 * D), s);
 #define CALL(TT)                                                                                                   \
     do {                                                                                                           \
         static bool attr = false;                                                                                  \

@@ -74,4 +74,14 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
+// ---- optional event profiler (runtime.cpp); a no-op unless ce_profile_enable(1) ----
+int ce_prof_begin(int cls, double flops, double bytes, hipStream_t s);
+void ce_prof_end(int idx, hipStream_t s);
+struct CeProfScope {
+    int idx;
+    hipStream_t s;
+    CeProfScope(int cls, double flops, double bytes, hipStream_t st) : idx(ce_prof_begin(cls, flops, bytes, st)), s(st) {}
+    ~CeProfScope() { ce_prof_end(idx, s); }
+};
+
 static inline int ce_div_up(long a, long b) { return (int)((a + b - 1) / b); }

@@ -260,6 +260,7 @@ extern "C" int ce_colsum_bf16(const void* x, long ld, float* out, int M, int N, 
     const int cap = (1024 + gx - 1) / gx;
     if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
+    CeProfScope prof(CE_PROF_COLSUM, (double)M * N, 2.0 * M * N, (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, M,
                        N);
     CE_LAUNCH_CHECK();

@@ -350,6 +350,8 @@ int launch_nt(const NTArgs& a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
+    const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
+    CeProfScope prof(CE_PROF_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
     CE_LAUNCH_CHECK();
     return 0;
@@ -419,6 +421,7 @@ extern "C" int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int 
                             TN_LDS_BYTES);
         attr_set = true;
     }
+    CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * Nn * Kk, 2.0 * ((double)M * Nn + (double)M * Kk) + 8.0 * Nn * Kk, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k * a.splits), dim3(256), TN_LDS_BYTES,
                        (hipStream_t)stream, a);
     CE_LAUNCH_CHECK();

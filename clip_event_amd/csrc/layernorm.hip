@@ -163,6 +163,7 @@ extern "C" int ce_layernorm_fwd(const float* x, long ldx, const int* rows, const
     CE_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "ce_layernorm_fwd: leading dimensions must be multiples of 4");
     dim3 grid(ce_div_up(M, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    CeProfScope prof(CE_PROF_LN_FWD, 8.0 * M * D, (4.0 + (out_f32 ? 4.0 : 2.0)) * M * D, s);
 #define CALL(IT)                                                                                                   \
     if (out_f32)                                                                                                   \
         hipLaunchKernelGGL((ln_fwd_kernel<IT, true>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps); \
@@ -184,6 +185,7 @@ extern "C" int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const flo
     if (blocks > 1024) blocks = 1024;
     dim3 grid(blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
+    CeProfScope prof(CE_PROF_LN_BWD, 16.0 * M * D, ((dy_f32 ? 4.0 : 2.0) + 4.0 + (dx_in ? 4.0 : 0.0) + 4.0 + (dxb ? 2.0 : 0.0)) * M * D, s);
 #define CALL(IT)                                                                                                    \
     if (dy_f32)                                                                                                     \
         hipLaunchKernelGGL((ln_bwd_kernel<IT, true>), grid, block, 0, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \

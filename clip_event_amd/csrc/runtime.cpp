@@ -1,7 +1,12 @@
-// Error reporting + version for the C ABI (no device code here).
+// Error reporting, version and the optional per-kernel-class event profiler of the C ABI.
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -15,3 +20,66 @@ void ce_set_error(const char* fmt, ...) {
 
 extern "C" const char* ce_last_error(void) { return g_err; }
 extern "C" int ce_version(void) { return 1; }
+
+// ---- profiler: HIP events recorded on the launch stream around every launch of a class ----
+namespace {
+struct Rec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+const char* kNames[CE_PROF_NCLASS] = {
+    "gemm_nt<BF16>", "gemm_nt<F32>", "gemm_nt<BIAS_BF16>", "gemm_nt<BIAS_F32>", "gemm_nt<BIAS_RESID_F32>",
+    "gemm_nt<BIAS_GELU>", "gemm_nt<GELUGRAD_BF16>", "gemm_tn", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd",
+    "colsum_bf16", "other"};
+}  // namespace
+
+int ce_prof_begin(int cls, double flops, double bytes, hipStream_t s) {
+    if (!g_on) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Rec r;
+    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    if (!g_pool.empty()) {
+        r.e0 = g_pool.back().first; r.e1 = g_pool.back().second; g_pool.pop_back();
+    } else {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+    }
+    hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
+}
+
+void ce_prof_end(int idx, hipStream_t s) {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx < (int)g_recs.size()) hipEventRecord(g_recs[idx].e1, s);
+}
+
+extern "C" void ce_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+}
+
+extern "C" const char* ce_profile_class_name(int cls) {
+    return (cls >= 0 && cls < CE_PROF_NCLASS) ? kNames[cls] : "?";
+}
+
+extern "C" int ce_profile_collect(double* out, int max_classes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int n = max_classes < CE_PROF_NCLASS ? max_classes : CE_PROF_NCLASS;
+    for (int i = 0; i < n * 4; ++i) out[i] = 0.0;
+    for (auto& r : g_recs) {
+        hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (r.cls >= 0 && r.cls < n) {
+            out[r.cls * 4 + 0] += 1.0;
+            out[r.cls * 4 + 1] += ms;
+            out[r.cls * 4 + 2] += r.flops;
+            out[r.cls * 4 + 3] += r.bytes;
+        }
+        g_pool.emplace_back(r.e0, r.e1);
+    }
+    g_recs.clear();
+    return n;
+}

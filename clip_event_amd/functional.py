@@ -236,9 +236,10 @@ class LogitsFn(torch.autograd.Function):
     s * I_local @ T_all^T, logits_per_text = s * T_local @ I_all^T."""
 
     @staticmethod
-    def forward(ctx, fi, ft, logit_scale, overbatch: bool):
+    def forward(ctx, fi, ft, logit_scale, overbatch: bool, want: str = "both"):
         cl, s = lib(), stream()
         dev = fi.device
+        ctx.set_materialize_grads(False)
         fi, ft = _f32(fi), _f32(ft)
         B, E = fi.shape
         N = ft.shape[0]
@@ -247,9 +248,13 @@ class LogitsFn(torch.autograd.Function):
         check(cl.ce_l2norm_fwd(ptr(fi), c_long(E), ptr(In), c_long(E), ptr(inv_i), c_int(B), c_int(E), s), "ce_l2norm_fwd")
         check(cl.ce_l2norm_fwd(ptr(ft), c_long(E), ptr(Tn), c_long(E), ptr(inv_t), c_int(N), c_int(E), s), "ce_l2norm_fwd")
         ls = logit_scale.detach().reshape(1)
-        lpt = _empty((N, B), torch.float32, dev)
-        _sgemm(Tn, E, 1, In, 1, E, lpt, N, B, E, alpha_ptr=ls, alpha_exp=1)          # s * T I^T
-        if overbatch:
+        lpt = None
+        if want in ("both", "text"):
+            lpt = _empty((N, B), torch.float32, dev)
+            _sgemm(Tn, E, 1, In, 1, E, lpt, N, B, E, alpha_ptr=ls, alpha_exp=1)      # s * T I^T
+        if want == "text":
+            lpi = None
+        elif overbatch:
             lpi = _empty((B, N), torch.float32, dev)
             _sgemm(In, E, 1, Tn, 1, E, lpi, B, N, E, alpha_ptr=ls, alpha_exp=1)      # s * I T^T
         else:
@@ -294,8 +299,10 @@ class LogitsFn(torch.autograd.Function):
                                c_int(0), s), "ce_l2norm_bwd")
         check(cl.ce_l2norm_bwd(ptr(dTn), c_long(E), ptr(Tn), c_long(E), ptr(inv_t), ptr(dft), c_long(E), c_int(N), c_int(E),
                                c_int(0), s), "ce_l2norm_bwd")
-        return dfi, dft, dls.reshape(()), None
+        return dfi, dft, dls.reshape(()), None, None
 
 
-def logits_from_features(image_features, text_features, logit_scale, overbatch: bool = True):
-    return LogitsFn.apply(image_features, text_features, logit_scale, bool(overbatch))
+def logits_from_features(image_features, text_features, logit_scale, overbatch: bool = True, want: str = "both"):
+    """``want`` in {"both", "image", "text"}: skip the logits matrix that is not needed (global-batch
+    path: each rank needs only its own row blocks)."""
+    return LogitsFn.apply(image_features, text_features, logit_scale, bool(overbatch), want)

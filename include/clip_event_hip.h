@@ -31,6 +31,18 @@ extern "C" {
 const char* ce_last_error(void);
 int ce_version(void);
 
+/* ---- optional profiler: HIP events on the launch stream around every launch, summed per kernel
+ * class.  ce_profile_collect fills out[class][4] = {launches, total ms, algorithmic FLOPs, algorithmic
+ * bytes} and resets.  Used by bench.py for the `roofline` object; off by default. ---- */
+enum {
+    CE_PROF_GEMM_NT0 = 0, /* + epilogue id (0..6) */
+    CE_PROF_GEMM_TN = 7, CE_PROF_ATTN_FWD = 8, CE_PROF_ATTN_BWD = 9, CE_PROF_LN_FWD = 10, CE_PROF_LN_BWD = 11,
+    CE_PROF_COLSUM = 12, CE_PROF_OTHER = 13, CE_PROF_NCLASS = 14
+};
+void ce_profile_enable(int on);
+int ce_profile_collect(double* out, int max_classes);
+const char* ce_profile_class_name(int cls);
+
 /* ---- GEMM epilogues (ce_gemm_nt) ---- */
 enum {
     CE_EPI_BF16 = 0,          /* out(bf16) = acc                                            */
