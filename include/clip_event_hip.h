@@ -169,6 +169,24 @@ int ce_tower_forward(const ce_tower_desc* d, int batch, const float* x0, void* w
  * parameter gradients are accumulated into the g_* buffers. */
 int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx, void* stream);
 
+/* ---- optimal-transport alignment + region pooling (ot.hip) ---- */
+/* dist[b] = trace(C_b T_b): cosine cost between txt[b] (M rows) and img[b] (N rows), IPOT plan
+ * (beta, `iters` outer iterations, 1 inner) computed without gradient; pads are uint8 [B,M]/[B,N].
+ * Strides in elements: batch stride, row stride (unit column stride).  T [B,N,M] and the inverse row
+ * norms are kept for the backward.  model_ot.py:8-83; M,N <= 64. */
+int ce_ot_fwd(const float* txt, long tsb, long tsr, const float* img, long isb, long isr,
+              const unsigned char* txt_pad, const unsigned char* img_pad, float* dist, float* T, float* txt_inv,
+              float* img_inv, int B, int M, int N, int D, float beta, int iters, void* stream);
+/* dtxt [B,M,D], dimg [B,N,D] (dense) for upstream grad[b] on dist[b] (gradient through the cost only) */
+int ce_ot_bwd(const float* txt, long tsb, long tsr, const float* img, long isb, long isr, const float* T,
+              const float* txt_inv, const float* img_inv, const float* grad, float* dtxt, float* dimg, int B, int M,
+              int N, int D, void* stream);
+/* out[i,:] = mean(grid[img_i, x0:x1, y0:y1, :]); boxes int32 [nbox,5] = {img,x0,y0,x1,y1}
+ * (model_clip.py:438-443; strides of the grid view in elements); backward adds into dense dgrid [B,g,g,E] */
+int ce_bbox_pool_fwd(const float* grid, long sb, long s0, long s1, const int* boxes, float* out, int nbox, int E,
+                     void* stream);
+int ce_bbox_pool_bwd(const float* dout, const int* boxes, float* dgrid, int g, int nbox, int E, void* stream);
+
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);
 int ce_probe_tr16(const void* image, int n_elems, const int* byte_off, void* out, void* stream);

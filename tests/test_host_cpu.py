@@ -1,0 +1,84 @@
+"""CPU (no GPU): host logic of the product, the C-ABI library's exports, and the loud failure
+when the HIP path cannot run."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import clip_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from clip_event_amd import build
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "clip_event_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(ce_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.ce_version.restype = ctypes.c_int
+    assert lib.ce_version() >= 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Argument validation happens before any launch: returns -EINVAL and a message."""
+    from clip_event_amd._lib import lib
+    cl = lib()
+    rc = cl.ce_gemm_nt(None, ctypes.c_long(8), None, ctypes.c_long(8), 0, 0, 0, 0, None, None, ctypes.c_long(0), None,
+                       ctypes.c_long(0), None, ctypes.c_long(0), None, ctypes.c_long(0), None)
+    assert rc == -22
+    assert b"empty problem" in cl.ce_last_error()
+
+
+def test_state_dict_keys_and_build_model_match_reference_layout():
+    from clip_event_amd.model import CLIP, build_model
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    sd = O.init_params(cfg, 3)
+    m = build_model({k: v.clone() for k, v in sd.items()})
+    assert list(m.state_dict().keys()) == list(O.param_shapes(cfg).keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(O.param_shapes(cfg)[k]) and torch.equal(v, sd[k])
+    assert m.training and m.visual.input_resolution == 64 and m.visual.patch_num == 2
+    assert m.dtype == torch.float32 and m.context_length == 20 and m.vocab_size == 512
+    m.set_hyps(constrastive_overbatch=False, alignment=True, multiattention=True)
+    assert (m.constrastive_overbatch, m.alignment, m.multiattention) == (False, True, True)
+    n_params = sum(p.numel() for p in CLIP(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12).parameters())
+    assert n_params == 151277313                      # ViT-B/32
+
+
+def test_no_cpu_fallback():
+    from clip_event_amd.model import build_model
+    from clip_event_amd._lib import HipExtensionMissing
+    from clip_event_amd.losses import CriterionContrastive
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    m = build_model(O.init_params(cfg, 3))
+    with pytest.raises(HipExtensionMissing):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 20, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        CriterionContrastive("ce")(torch.zeros(2, 2), torch.zeros(2, 2), None, None, index_pos=torch.arange(2))
+    with pytest.raises(RuntimeError):
+        CriterionContrastive("hinge")
+
+
+def test_global_labels_match_single_process_layout():
+    from clip_event_amd.distributed import global_labels
+    for overbatch in (True, False):
+        yi, yt, ip = global_labels(4, 1, 2, overbatch, rank_=0)
+        ri, rt, rp = O.build_labels(4, 1, 2, overbatch)
+        assert torch.equal(yi, ri) and torch.equal(yt, rt) and torch.equal(ip, rp)
+    # rank 1 of W=2, B=3, K=2: images 3..5, positive columns (3..5)*2, local positive rows 0,2,4
+    yi, yt, ip = global_labels(3, 1, 1, True, rank_=1)
+    assert yi.tolist() == [6, 8, 10] and yt.tolist() == [3, 3, 4, 4, 5, 5] and ip.tolist() == [0, 2, 4]
+
+
+def test_patch_from_norm_bbox_integer_contract():
+    from clip_event_amd import patch_from_norm_bbox
+    from tests.util import golden_json
+    assert patch_from_norm_bbox((0.1, 0.1, 0.6, 0.7), 7) == (0, 0, 5, 5)       # SURVEY.md R2 [probed]
+    for case in golden_json()["region"]["bbox7"]:
+        assert list(patch_from_norm_bbox(tuple(case["bbox"]), 7)) == case["idx"]

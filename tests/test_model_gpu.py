@@ -173,3 +173,97 @@ def test_train_step_fused_adam():
             worst = min(worst, _cos(d_hip, d_ref))
     print("worst parameter-delta cosine after 2 Adam steps:", worst)
     assert worst > 0.9
+
+
+def test_ot_alignment_against_reference_golden():
+    """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
+    recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""
+    from clip_event_amd.losses import CriterionAlignment
+    from clip_event_amd.ot import optimal_transport_dist
+    from tests.util import golden_json, golden_npz
+    G = golden_json()["ot"]
+    Z = golden_npz("ot.npz")
+    txt = torch.from_numpy(Z["txt"]).to(DEV)
+    obj = torch.from_numpy(Z["obj"]).to(DEV)
+    tn, on = torch.from_numpy(Z["txt_num"]).to(DEV), torch.from_numpy(Z["obj_num"]).to(DEV)
+    d = optimal_transport_dist(txt, obj[:, 1:], tn == 0, on[:, 1:] == 0).cpu().numpy()
+    print("ot dist", d, "ref", Z["dist"])
+    np.testing.assert_allclose(d, Z["dist"], rtol=2e-4, atol=1e-5)     # includes the all-pad samples (0)
+    ld = CriterionAlignment()(txt, obj, tn, on)
+    assert abs(float(ld["loss_ot"]) - G["loss_ot"]) < 1e-4 * max(1.0, abs(G["loss_ot"]))
+    t2 = torch.from_numpy(Z["txt2"]).to(DEV).requires_grad_(True)
+    o2 = torch.from_numpy(Z["obj2"]).to(DEV).requires_grad_(True)
+    l2 = CriterionAlignment()(t2, o2, torch.from_numpy(Z["txt_num2"]).to(DEV), torch.from_numpy(Z["obj_num2"]).to(DEV))["loss_ot"]
+    assert abs(float(l2) - G["loss_ot2"]) < 1e-4 * max(1.0, abs(G["loss_ot2"]))
+    l2.backward()
+    print("ot grad rel", _rel(t2.grad, torch.from_numpy(Z["grad_txt2"])), _rel(o2.grad, torch.from_numpy(Z["grad_obj2"])))
+    assert _rel(t2.grad, torch.from_numpy(Z["grad_txt2"])) < 2e-3
+    assert _rel(o2.grad, torch.from_numpy(Z["grad_obj2"])) < 2e-3
+    assert float(o2.grad[:, 0].abs().max()) == 0.0
+
+
+def test_region_branch_against_reference_golden():
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from tests.util import golden_json, summary_of
+    G = golden_json()
+    cfg = O.ClipConfig(**G["tiny"]["cfg"])
+    R = G["region"]
+    B = 5
+    img = S.synthetic_images(B, cfg.image_resolution, seed=41).to(DEV)
+    txt = S.synthetic_tokens(B, cfg.context_length, cfg.vocab_size, seed=42, min_len=2).to(DEV)
+    bboxs = [[None if b is None else tuple(b) for b in bb] for bb in R["bboxs"]]
+    desc = [S.synthetic_tokens(len(b), cfg.context_length, cfg.vocab_size, seed=50 + i, min_len=2) for i, b in enumerate(bboxs)]
+    lab = [S.synthetic_tokens(len(b), cfg.context_length, cfg.vocab_size, seed=60 + i, min_len=2) for i, b in enumerate(bboxs)]
+    for mode in ("desc", "desc_type", "desc_type_text"):
+        m, sd = _mk(cfg, 11)
+        out = m(img, txt, train_arg=mode, bboxs=bboxs, bbox_desc_vec=desc, bbox_label_vec=lab)
+        assert len(out) == 4
+        li, lt, lb, la = out
+        print(f"[{mode}] loss_per_bbox {float(lb):.4f} (ref {R[mode]['loss_per_bbox']:.4f}) loss_per_arg {float(la):.4f} (ref {R[mode]['loss_per_arg']:.4f})")
+        assert abs(float(lb) - R[mode]["loss_per_bbox"]) < 5e-2
+        assert abs(float(la) - R[mode]["loss_per_arg"]) < 5e-2
+        assert (li.detach().cpu() - torch.tensor(R[mode]["logits_per_image"])).abs().max() < 0.15
+        (lb + la).backward()
+        torch.cuda.synchronize()
+        bad = []
+        for n, p in m.named_parameters():
+            gs = R[mode]["grads"].get(n)
+            if gs is None or gs["norm"] == 0.0:
+                continue
+            norm, _, _ = summary_of(p.grad, gs["idx"])
+            if abs(norm - gs["norm"]) > 0.1 * gs["norm"] + 1e-6:
+                bad.append((n, norm, gs["norm"]))
+        print(f"[{mode}] params with >10% grad-norm deviation:", bad[:6])
+        assert not bad
+
+
+def test_sim_entity_alignment_through_towers():
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionAlignment
+    from tests.util import golden_json, golden_npz, summary_of
+    G = golden_json()
+    Z = golden_npz("entity.npz")
+    cfg = O.ClipConfig(**G["tiny"]["cfg"])
+    m, sd = _mk(cfg, 11)
+    B, O_, M = 3, 4, 5
+    rng = np.random.default_rng(88)
+    obj = torch.from_numpy(rng.standard_normal((B, O_, 3, cfg.image_resolution, cfg.image_resolution), dtype=np.float32)).to(DEV)
+    ent = S.synthetic_tokens(B * M, cfg.context_length, cfg.vocab_size, seed=89, min_len=2).view(B, M, -1).to(DEV)
+    fi, ft = m.sim_entity(obj, ent)
+    assert _cos(fi, torch.from_numpy(Z["image_features"])) > 0.9995 and _cos(ft, torch.from_numpy(Z["text_features"])) > 0.9995
+    ld = CriterionAlignment()(ft, fi, torch.from_numpy(Z["ent_num"]).to(DEV), torch.from_numpy(Z["obj_num"]).to(DEV))
+    print(f"loss_ot {float(ld['loss_ot']):.5f} (ref {G['entity']['loss_ot']:.5f})")
+    assert abs(float(ld["loss_ot"]) - G["entity"]["loss_ot"]) < 2e-3
+    ld["loss_ot"].backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        gs = G["entity"]["grads"].get(n)
+        if gs is None or gs["norm"] < 1e-7:
+            continue
+        norm, _, _ = summary_of(p.grad, gs["idx"])
+        worst = max(worst, abs(norm - gs["norm"]) / gs["norm"])
+    print("worst relative grad-norm deviation:", worst)
+    assert worst < 0.15
