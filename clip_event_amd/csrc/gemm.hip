@@ -21,6 +21,8 @@
 // footprint of a half-wave).  Output columns sit on the lane (col = lane&31), so every
 // accumulator register is two 128-byte row segments: the full-rate shape for
 // global_atomic_add_f32.  The M range is split across workgroups to fill the chip.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
@@ -53,6 +55,36 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7;
     int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + local;
+}
+
+// fused epilogue for one lane's 4 consecutive output columns n..n+3 of row m
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4 v) {
+    if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                  EPI == CE_EPI_BIAS_F32) {
+        v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
+    } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
+        v += *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
+    } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
+        // out = pre-activation a (bf16, kept for the backward), out2 = QuickGELU(a) (bf16)
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+        u32x2 g = {pack_bf2(quick_gelu_f(v[0]), quick_gelu_f(v[1])), pack_bf2(quick_gelu_f(v[2]), quick_gelu_f(v[3]))};
+        *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = g;
+    } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        // out = acc * QuickGELU'(a), a = saved bf16 pre-activation
+        u32x2 a = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
+        u32x2 o = {pack_bf2(v[0] * quick_gelu_grad_f(bf_lo(a[0])), v[1] * quick_gelu_grad_f(bf_hi(a[0]))),
+                   pack_bf2(v[2] * quick_gelu_grad_f(bf_lo(a[1])), v[3] * quick_gelu_grad_f(bf_hi(a[1])))};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    }
 }
 
 template <int EPI>
@@ -150,34 +182,164 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
         for (int nt = 0; nt < 4; ++nt) {
             const int n = en + nt * 16;
             if (n >= p.N) continue;
-            f32x4 v = acc[mt][nt];
-            if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
-                          EPI == CE_EPI_BIAS_F32) {
-                f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v += b;
+            nt_epilogue<EPI>(p, m, n, acc[mt][nt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), operands staged straight
+// into LDS by global_load_lds (LDS-DMA, 16 B per lane): no VGPR round trip and no ds_write
+// issue cost, which is what bounds the 128^2 register-staged kernel.  The DMA destination is
+// lane-linear, so the XOR swizzle (chunk ^= row&7) is applied to the per-lane SOURCE address
+// and again on the fragment reads.  One barrier per K-tile, next tile in flight during the MFMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int N2_BM = 256, N2_BN = 256, N2_BK = 64;
+constexpr int N2_TILE_BYTES = N2_BM * N2_BK * 2;            // 32 KiB per operand
+constexpr int N2_STAGE_BYTES = 2 * N2_TILE_BYTES;           // 64 KiB
+constexpr int N2_LDS_BYTES = 8 * 64 * 272;                 // 136 KiB: 2 stages (128 KiB) or 8 epilogue slices of 17 KiB
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * N2_BM, n0 = tn * N2_BN;
+
+    // staging: one wave-instruction = 8 rows x 128 B; wave w, instruction i covers rows (w*4+i)*8 .. +7.
+    // lane l lands at LDS (row r = l>>3, position pos = l&7) and therefore fetches chunk pos ^ (r&7).
+    const int s_r = lane >> 3, s_pos = lane & 7;
+    const int s_chunk = s_pos ^ s_r;
+    const bf16_t* gA[4];
+    const bf16_t* gB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + s_r;
+        const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);   // clamp: rows past the edge are never stored
+        gA[i] = p.A + (long)ra * p.lda + s_chunk * 8;
+        gB[i] = p.B + (long)rb * p.ldb + s_chunk * 8;
+    }
+    auto stage = [&](int st, int kt) {
+        char* sa = smem + st * N2_STAGE_BYTES + wave * 4096;
+        char* sb = sa + N2_TILE_BYTES;
+        const int koff = kt * N2_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gA[i] + koff), (lptr_t*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gB[i] + koff), (lptr_t*)(sb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / N2_BK;
+    stage(0, 0);
+    __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+
+    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
+    const int fa_base = (wm * 128 + f_row) * 128;
+    const int fb_base = N2_TILE_BYTES + (wn * 64 + f_row) * 128;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* st = smem + cur * N2_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + f_kc) ^ f_sw) << 4;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + (mh * 4 + t) * 2048 + coff);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mh * 4 + t][nt] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[mh * 4 + t][nt], 0, 0, 0);
             }
-            if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
-            } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
-            } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
-                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + n);
-                v += r;
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
-            } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
-                // out = pre-activation a (bf16, kept for the backward), out2 = QuickGELU(a) (bf16)
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
-                u32x2 g = {pack_bf2(quick_gelu_f(v[0]), quick_gelu_f(v[1])),
-                           pack_bf2(quick_gelu_f(v[2]), quick_gelu_f(v[3]))};
-                *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = g;
-            } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
-                // out = acc * QuickGELU'(a), a = saved bf16 pre-activation
-                u32x2 a = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
-                u32x2 o = {pack_bf2(v[0] * quick_gelu_grad_f(bf_lo(a[0])), v[1] * quick_gelu_grad_f(bf_hi(a[0]))),
-                           pack_bf2(v[2] * quick_gelu_grad_f(bf_lo(a[1])), v[3] * quick_gelu_grad_f(bf_hi(a[1])))};
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: each wave transposes its 128x64 fp32 sub-tile in two 64x64 halves
+    // inside its own 17 KiB slice (row stride 272 B), then every instruction reads/writes global
+    // memory as 8 rows x 32 B..256 B contiguous: 16 B per lane, whole cache lines per row.
+    // (the loop's last barrier guarantees every wave is done with the operand stages)
+    constexpr int EROW = 272;
+    char* ebuf = smem + wave * (64 * EROW);
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;          // row-phase map: row e_r (+8/iter), 8 columns
+    const int gn = n0 + wn * 64 + e_c;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                  EPI == CE_EPI_BIAS_F32) {
+        if (gn < p.N) {
+            bias0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+            bias1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+        }
+    }
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(ebuf + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) =
+                    acc[mh * 4 + t][nt];
+        const int gm0 = m0 + wm * 128 + mh * 64 + e_r;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = gm0 + it * 8;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
+            if (m < p.M && gn < p.N) {
+                v0 += bias0;
+                v1 += bias1;
+                if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
+                    u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
+                } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
+                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + gn;
+                    *reinterpret_cast<f32x4*>(o) = v0;
+                    *reinterpret_cast<f32x4*>(o + 4) = v1;
+                } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
+                    const float* r = p.resid + (long)m * p.ldr + gn;
+                    v0 += *reinterpret_cast<const f32x4*>(r);
+                    v1 += *reinterpret_cast<const f32x4*>(r + 4);
+                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + gn;
+                    *reinterpret_cast<f32x4*>(o) = v0;
+                    *reinterpret_cast<f32x4*>(o + 4) = v1;
+                } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
+                    u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
+                    u32x4 g = {pack_bf2(quick_gelu_f(v0[0]), quick_gelu_f(v0[1])), pack_bf2(quick_gelu_f(v0[2]), quick_gelu_f(v0[3])),
+                               pack_bf2(quick_gelu_f(v1[0]), quick_gelu_f(v1[1])), pack_bf2(quick_gelu_f(v1[2]), quick_gelu_f(v1[3]))};
+                    *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + gn) = g;
+                } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+                    u32x4 a = *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + gn);
+                    u32x4 o = {pack_bf2(v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0]))),
+                               pack_bf2(v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))),
+                               pack_bf2(v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2]))),
+                               pack_bf2(v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3])))};
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
+                }
             }
         }
     }
@@ -342,17 +504,37 @@ __global__ void probe_tr16_kernel(const uint16_t* image, int n_elems, const int*
     out[threadIdx.x] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + byte_off[threadIdx.x]));
 }
 
+int nt_variant() {   // CE_GEMM_NT=128|256 forces a tile; default: pick per shape
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CE_GEMM_NT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int EPI>
-int launch_nt(const NTArgs& a, hipStream_t stream) {
+int launch_nt(NTArgs a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
         attr_set = true;
     }
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
     CeProfScope prof(CE_PROF_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
+    const int force = nt_variant();
+    const bool can256 = (a.K % N2_BK == 0) && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo2 % 8 == 0 && a.ldaux % 8 == 0;
+    const bool want256 = force == 256 || (force == 0 && a.M >= 1024 && a.N >= 256);
+    if (can256 && want256) {
+        a.tiles_m = ce_div_up(a.M, N2_BM);
+        a.tiles_n = ce_div_up(a.N, N2_BN);
+        hipLaunchKernelGGL(gemm_nt256_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+    } else {
+        hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
+    }
     CE_LAUNCH_CHECK();
     return 0;
 }
