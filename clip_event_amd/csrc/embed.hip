@@ -118,25 +118,43 @@ __global__ void batch_reduce_kernel(const float* __restrict__ x, float* __restri
     *reinterpret_cast<f32x4*>(out + i4) = acc;
 }
 
-// out[n] += sum_m x[m, n] ; block = 4 waves over different rows of the same 256 columns
+// out[n] += sum_m x[m, n].  Block = 32 column groups (8 bf16 = 16 B per lane) x 8 row groups over a
+// 64-row slab; 4 independent 16-byte loads in flight per thread; LDS reduce over the row groups,
+// then one atomic per column per block.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ out,
                                                           int M, int N) {
-    __shared__ f32x4 red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float red[8][257];
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 256 + cg * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < N) {
-        for (int r = blockIdx.y * 4 + wave; r < M; r += gridDim.y * 4) {
-            u32x2 pk = *reinterpret_cast<const u32x2*>(x + (long)r * ld + c);
-            acc += f32x4{bf_lo(pk[0]), bf_hi(pk[0]), bf_lo(pk[1]), bf_hi(pk[1])};
+        const int r0 = blockIdx.y * 64 + rg;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + (h * 4 + u) * 8;
+                v[u] = (r < M) ? *reinterpret_cast<const u32x4*>(x + (long)r * ld + c) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += bf_lo(v[u][e]);
+                    acc[2 * e + 1] += bf_hi(v[u][e]);
+                }
         }
     }
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && c < N) {
-        f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, t[e]);
+    for (int e = 0; e < 8; ++e) red[rg][cg * 8 + e] = acc[e];
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+        atomicAdd(out + col, t);
     }
 }
 
@@ -254,12 +272,9 @@ extern "C" int ce_batch_reduce(const float* x, float* out, int B, long slab, lon
 }
 
 extern "C" int ce_colsum_bf16(const void* x, long ld, float* out, int M, int N, void* stream) {
-    CE_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "ce_colsum_bf16: bad shape");
+    CE_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "ce_colsum_bf16: N and ld must be multiples of 8");
     const int gx = ce_div_up(N, 256);
-    int gy = ce_div_up(M, 4 * 16);
-    const int cap = (1024 + gx - 1) / gx;
-    if (gy > cap) gy = cap;
-    if (gy < 1) gy = 1;
+    const int gy = ce_div_up(M, 64);
     CeProfScope prof(CE_PROF_COLSUM, (double)M * N, 2.0 * M * N, (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, M,
                        N);

@@ -481,6 +481,153 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// TN kernel v2: same tile and MFMA decomposition, operands staged by LDS-DMA
+// (buffer_load ... lds, bounds-checked so contraction rows past M arrive as zeros) into
+// unpadded 256-byte rows; the bank-conflict fix for the transposed reads moves into an XOR
+// swizzle of the 16-byte chunk index with (row&3)<<2, applied to the DMA source address and to
+// the read address.  Optionally fuses the bias gradient: the waves of the k-tile-0 column
+// accumulate sum_m P[m][n] with one extra MFMA against an all-ones operand.
+// ------------------------------------------------------------------------------------------
+constexpr int T2_TILE_BYTES = TN_BM * 256;               // 16 KiB per operand
+constexpr int T2_STAGE_BYTES = 2 * T2_TILE_BYTES;        // 32 KiB
+constexpr int T2_LDS_BYTES = 2 * T2_STAGE_BYTES;         // 64 KiB
+
+__device__ __forceinline__ bf16x8 tr_frag2(const char* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __restrict__ bias_grad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.splits;
+    bid /= p.splits;
+    const int tk = bid % p.tiles_k, tn = bid / p.tiles_k;
+    const int n0 = tn * TN_BN, k0 = tk * TN_BK;
+    const int ms = split * p.m_per_split;
+    const int me = min(p.M, ms + p.m_per_split);
+    if (ms >= me) return;  // uniform per block
+    const int rows = me - ms;
+
+    __amdgpu_buffer_rsrc_t rP = make_rsrc(p.P + (long)ms * p.ldp, (uint32_t)((long)rows * p.ldp * 2));
+    __amdgpu_buffer_rsrc_t rQ = make_rsrc(p.Q + (long)ms * p.ldq, (uint32_t)((long)rows * p.ldq * 2));
+
+    // DMA map: instruction (wave*4 + j) fills rows (wave*4+j)*4 .. +3; lane -> row r = lane>>4, position lane&15,
+    // source chunk = position ^ (r<<2)
+    const int s_r = lane >> 4;
+    const int s_chunk = (lane & 15) ^ (s_r << 2);
+    uint32_t vP[4], vQ[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 4 + s_r;
+        vP[j] = (uint32_t)(row * p.ldp * 2 + (n0 + s_chunk * 8) * 2);
+        vQ[j] = (uint32_t)(row * p.ldq * 2 + (k0 + s_chunk * 8) * 2);
+    }
+    auto stage = [&](int st, int mt) {
+        char* sp = smem + st * T2_STAGE_BYTES + wave * 4096;
+        char* sq = sp + T2_TILE_BYTES;
+        const uint32_t mbP = (uint32_t)((long)mt * TN_BM * p.ldp * 2);
+        const uint32_t mbQ = (uint32_t)((long)mt * TN_BM * p.ldq * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (lptr_t*)(sp + j * 1024), 16, vP[j] + mbP, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ, (lptr_t*)(sq + j * 1024), 16, vQ[j] + mbQ, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+    f32x16 accb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+        accb[0][r] = 0.f; accb[1][r] = 0.f;
+    }
+    // bias-gradient work is spread evenly: of every (2*tiles_k) contraction steps of a (tn, split) column,
+    // the wave (tk, wk) takes one, so no workgroup carries more MFMAs than the others
+    const int bias_mod = 2 * p.tiles_k, bias_me = 2 * tk + wk;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    // transposed-read addresses (see v1) on 256-byte rows with the chunk swizzle
+    const int g = lane >> 4, li = lane & 15;
+    const int t_row = 8 * (g >> 1) + (li >> 2);
+    const int t_sw = (li >> 2) << 2;
+    const int t_cb = 2 * (g & 1) + ((li & 3) >> 1);
+    int offP[2], offQ[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        offP[t] = t_row * 256 + (((wn * 8 + t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
+        offQ[t] = T2_TILE_BYTES + t_row * 256 + (((wk * 8 + t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
+    }
+
+    const int nmt = (rows + TN_BM - 1) / TN_BM;
+    stage(0, 0);
+    __syncthreads();
+    int bturn = bias_me;   // this wave takes the bias MFMAs of every bias_mod-th m-tile (wave-uniform countdown)
+    for (int mt = 0; mt < nmt; ++mt) {
+        const int cur = mt & 1;
+        if (mt + 1 < nmt) stage(cur ^ 1, mt + 1);
+        const char* st = smem + cur * T2_STAGE_BYTES;
+        const bool bias_now = BIAS && (bturn == 0);
+        bturn = (bturn == 0) ? bias_mod - 1 : bturn - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 pf[2], qf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pf[t] = tr_frag2(st + offP[t] + s * 16 * 256);
+                qf[t] = tr_frag2(st + offQ[t] + s * 16 * 256);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
+            if (bias_now) {
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0], ones, accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[1], ones, accb[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int ek = k0 + wk * 64 + (lane & 31);
+    const int en = n0 + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k = ek + kt * 32;
+            if (k >= p.Kk) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+                if (n < p.Nn) atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
+            }
+        }
+    if (BIAS && (lane & 31) == 0) {   // every column of accb holds the same row sums: take column 0
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+                if (n < p.Nn) atomicAdd(bias_grad + n, accb[nt][r]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // probes: raw fragment in / raw accumulator out, so the host can check the lane maps
 // ------------------------------------------------------------------------------------------
 __global__ void probe_mfma16_kernel(const bf16x8* a, const bf16x8* b, f32x4* out) {
@@ -580,6 +727,11 @@ extern "C" int ce_gemm_nt(const void* A, long lda, const void* B, long ldb, int 
 
 extern "C" int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out,
                           long ldo, int splits, void* stream) {
+    return ce_gemm_tn_bias(P, ldp, Q, ldq, M, Nn, Kk, out, ldo, nullptr, splits, stream);
+}
+
+extern "C" int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out,
+                               long ldo, float* bias_grad, int splits, void* stream) {
     CE_CHECK_ARG(M > 0 && Nn > 0 && Kk > 0, "ce_gemm_tn: empty problem");
     CE_CHECK_ARG(Nn % 8 == 0 && Kk % 8 == 0 && ldp % 8 == 0 && ldq % 8 == 0, "ce_gemm_tn: Nn,Kk,ldp,ldq must be multiples of 8");
     CE_CHECK_ARG(ldp >= Nn && ldq >= Kk && ldo >= Kk, "ce_gemm_tn: leading dimension smaller than the row");
@@ -588,9 +740,9 @@ extern "C" int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int 
     a.M = M; a.Nn = Nn; a.Kk = Kk;
     a.tiles_n = ce_div_up(Nn, TN_BN); a.tiles_k = ce_div_up(Kk, TN_BK);
     const int m_tiles = ce_div_up(M, TN_BM);
-    if (splits <= 0) {  // fill ~2 workgroups per CU
+    if (splits <= 0) {  // one resident round: at most 2 workgroups per CU (512 slots), never a ragged second round
         const int tiles = a.tiles_n * a.tiles_k;
-        splits = (512 + tiles - 1) / tiles;
+        splits = 512 / tiles;
     }
     if (splits > m_tiles) splits = m_tiles;
     if (splits < 1) splits = 1;
@@ -598,14 +750,34 @@ extern "C" int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int 
     a.splits = ce_div_up(M, a.m_per_split);
     CE_CHECK_ARG((long)a.m_per_split * (ldp > ldq ? ldp : ldq) * 2 < (1L << 32), "ce_gemm_tn: split exceeds 4 GiB");
     static bool attr_set = false;
+    static int variant = 2;   // CE_GEMM_TN=1 forces the register-staged v1 kernel
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TN_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+        const char* e = getenv("CE_GEMM_TN");
+        if (e) variant = atoi(e);
         attr_set = true;
     }
-    CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * Nn * Kk, 2.0 * ((double)M * Nn + (double)M * Kk) + 8.0 * Nn * Kk, (hipStream_t)stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k * a.splits), dim3(256), TN_LDS_BYTES,
-                       (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(a.tiles_n * a.tiles_k * a.splits);
+    if (variant == 1) {
+        {
+            CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * Nn * Kk, 2.0 * ((double)M * Nn + (double)M * Kk) + 8.0 * Nn * Kk, s);
+            hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), TN_LDS_BYTES, s, a);
+        }
+        CE_LAUNCH_CHECK();
+        if (bias_grad) return ce_colsum_bf16(P, ldp, bias_grad, M, Nn, stream);
+        return 0;
+    }
+    CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * Nn * Kk, 2.0 * ((double)M * Nn + (double)M * Kk) + 8.0 * Nn * Kk, s);
+    if (bias_grad)
+        hipLaunchKernelGGL(gemm_tn2_kernel<true>, grid, dim3(256), T2_LDS_BYTES, s, a, bias_grad);
+    else
+        hipLaunchKernelGGL(gemm_tn2_kernel<false>, grid, dim3(256), T2_LDS_BYTES, s, a, bias_grad);
     CE_LAUNCH_CHECK();
     return 0;
 }

@@ -70,15 +70,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ dx_in,
                                                      float* __restrict__ dx_out, long lddx, bf16_t* __restrict__ dxb,
-                                                     long lddxb, float* __restrict__ dw, float* __restrict__ db, int M,
-                                                     int D) {
+                                                     long lddxb, float* __restrict__ dw, float* __restrict__ db,
+                                                     float* __restrict__ dxsum, int M, int D) {
     __shared__ float red[4 * 2048];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 aw[IT], ab[IT], g[IT];
+    f32x4 aw[IT], ab[IT], ax[IT], g[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ax[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int c = i * 256 + lane * 4;
         g[i] = (c < D) ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 f32x4 o = (gy[i] - c1 - xh[i] * c2) * rs;
                 if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + dst * lddx + c);
                 *reinterpret_cast<f32x4*>(dx_out + dst * lddx + c) = o;
+                ax[i] += o;
                 if (dxb) {
                     u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
                     *reinterpret_cast<u32x2*>(dxb + dst * lddxb + c) = pk;
@@ -129,15 +131,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
     // cross-wave reduce of the dgamma / dbeta partials, then one atomic per column per block
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (dxsum ? 3 : 2); ++pass) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = i * 256 + lane * 4;
-            if (c < D) *reinterpret_cast<f32x4*>(&red[wave * 2048 + c]) = pass == 0 ? aw[i] : ab[i];
+            if (c < D) *reinterpret_cast<f32x4*>(&red[wave * 2048 + c]) = pass == 0 ? aw[i] : (pass == 1 ? ab[i] : ax[i]);
         }
         __syncthreads();
-        float* dstp = pass == 0 ? dw : db;
+        float* dstp = pass == 0 ? dw : (pass == 1 ? db : dxsum);
         for (int c = threadIdx.x; c < D; c += 256) {
             float t = (red[c] + red[2048 + c]) + (red[4096 + c] + red[6144 + c]);
             atomicAdd(dstp + c, t);
@@ -177,8 +179,8 @@ extern "C" int ce_layernorm_fwd(const float* x, long ldx, const int* rows, const
 
 extern "C" int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const float* x, long ldx, const int* rows,
                                 const float* mean, const float* rstd, const float* w, const float* dx_in,
-                                float* dx_out, long lddx, void* dxb, long lddxb, float* dw, float* db, int M, int D,
-                                void* stream) {
+                                float* dx_out, long lddx, void* dxb, long lddxb, float* dw, float* db, float* dxsum, int M,
+                                int D, void* stream) {
     CE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "ce_layernorm_bwd: need 0<D<=2048, D%%4==0 (D=%d M=%d)", D, M);
     CE_CHECK_ARG(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && lddxb % 4 == 0, "ce_layernorm_bwd: leading dimensions must be multiples of 4");
     int blocks = ce_div_up(M, 4);
@@ -189,10 +191,10 @@ extern "C" int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const flo
 #define CALL(IT)                                                                                                    \
     if (dy_f32)                                                                                                     \
         hipLaunchKernelGGL((ln_bwd_kernel<IT, true>), grid, block, 0, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \
-                           dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, M, D);                                        \
+                           dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, dxsum, M, D);                                        \
     else                                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<IT, false>), grid, block, 0, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \
-                           dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, M, D)
+                           dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, dxsum, M, D)
     LN_DISPATCH(D, CALL);
 #undef CALL
     CE_LAUNCH_CHECK();

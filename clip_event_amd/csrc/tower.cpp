@@ -135,7 +135,7 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         TRY(ce_gemm_nt(L.dxb, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.da, 4 * w, nullptr,
                        0, s.a, 4 * w, stream));                                   // da = (dx Wp) * gelu'(a)
         TRY(ce_gemm_tn(L.dxb, w, s.g, 4 * w, M, w, 4 * w, p.g_w_proj, 4 * w, 0, stream));
-        TRY(ce_colsum_bf16(L.dxb, w, p.g_b_proj, M, w, stream));
+        if (l == d->layers - 1) TRY(ce_colsum_bf16(L.dxb, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
         // ---- mlp.c_fc : a = h2 Wf^T + bf ----
         TRY(ce_gemm_nt(L.da, 4 * w, p.wt_fc, 4 * w, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh2 = da Wf
@@ -143,12 +143,11 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         TRY(ce_colsum_bf16(L.da, 4 * w, p.g_b_fc, M, 4 * w, stream));
         // ---- ln_2 (+ residual) ----
         TRY(ce_layernorm_bwd(L.dh, w, 0, s.x_mid, w, nullptr, s.mean2, s.rstd2, p.ln2_w, dx, dx, w, L.dxb, w, p.g_ln2_w,
-                             p.g_ln2_b, M, w, stream));
+                             p.g_ln2_b, p.g_b_out, M, w, stream));
         // ---- attn.out_proj : x_mid = x_in + o Wo^T + bo ----
         TRY(ce_gemm_nt(L.dxb, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
                        stream));                                                  // d_o = dx Wo
-        TRY(ce_gemm_tn(L.dxb, w, s.o, w, M, w, w, p.g_w_out, w, 0, stream));
-        TRY(ce_colsum_bf16(L.dxb, w, p.g_b_out, M, w, stream));
+        TRY(ce_gemm_tn(L.dxb, w, s.o, w, M, w, w, p.g_w_out, w, 0, stream));          // bias grad: fused in ln_2's backward
         // ---- attention core ----
         TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
                              stream));
@@ -159,7 +158,7 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         TRY(ce_colsum_bf16(L.dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
         // ---- ln_1 (+ residual) ----
         TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb, w, p.g_ln1_w,
-                             p.g_ln1_b, M, w, stream));
+                             p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
     }
     return 0;
 }

@@ -118,7 +118,7 @@ class EncodeImageFn(torch.autograd.Function):
         dx = torch.zeros((M, D), dtype=torch.float32, device=dev) if rows is not None else _empty((M, D), torch.float32, dev)
         check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), ptr(rows), ptr(mean_post),
                                   ptr(rstd_post), ptr(P["visual.ln_post.weight"]), None, ptr(dx), c_long(D), None,
-                                  c_long(0), ptr(G("visual.ln_post.weight")), ptr(G("visual.ln_post.bias")), c_int(n),
+                                  c_long(0), ptr(G("visual.ln_post.weight")), ptr(G("visual.ln_post.bias")), None, c_int(n),
                                   c_int(D), s), "ce_layernorm_bwd(ln_post)")
         check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), s),
               "ce_tower_backward(vision)")
@@ -127,7 +127,7 @@ class EncodeImageFn(torch.autograd.Function):
         dxpre = _empty((M, D), torch.float32, dev)
         check(cl.ce_layernorm_bwd(ptr(dx), c_long(D), c_int(1), ptr(xpre), c_long(D), None, ptr(mean_pre), ptr(rstd_pre),
                                   ptr(P["visual.ln_pre.weight"]), None, ptr(dxpre), c_long(D), None, c_long(0),
-                                  ptr(G("visual.ln_pre.weight")), ptr(G("visual.ln_pre.bias")), c_int(M), c_int(D), s),
+                                  ptr(G("visual.ln_pre.weight")), ptr(G("visual.ln_pre.bias")), None, c_int(M), c_int(D), s),
               "ce_layernorm_bwd(ln_pre)")
         # positional / class embedding gradients: sums over the batch axis
         check(cl.ce_batch_reduce(ptr(dxpre), ptr(G("visual.positional_embedding")), c_int(B), c_long(T * D),
@@ -210,7 +210,7 @@ class EncodeTextFn(torch.autograd.Function):
         dx = torch.zeros((M, D), dtype=torch.float32, device=dev)
         check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), ptr(rows), ptr(mean_f), ptr(rstd_f),
                                   ptr(P["ln_final.weight"]), None, ptr(dx), c_long(D), None, c_long(0),
-                                  ptr(G("ln_final.weight")), ptr(G("ln_final.bias")), c_int(n), c_int(D), s),
+                                  ptr(G("ln_final.weight")), ptr(G("ln_final.bias")), None, c_int(n), c_int(D), s),
               "ce_layernorm_bwd(ln_final)")
         check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(dx), s),
               "ce_tower_backward(text)")

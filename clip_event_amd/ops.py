@@ -59,7 +59,7 @@ def layernorm_fwd(x: torch.Tensor, w, b, *, rows=None, out_f32=False, eps=1e-5, 
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, rows=None, dx_in=None, dx_out=None, dxb=None):
+def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, rows=None, dx_in=None, dx_out=None, dxb=None, dxsum=None):
     """dx_out = dx_in + LN'(dy); dxb = bf16(dx_out); dw += ..., db += ... (atomic)."""
     M = dy.shape[0]
     D = dy.shape[1]
@@ -68,7 +68,7 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, rows=None, dx_in=None, dx_out
     check(lib().ce_layernorm_bwd(ptr(dy), c_long(dy.stride(0)), c_int(1 if dy.dtype == torch.float32 else 0), ptr(x),
                                  c_long(x.stride(0)), ptr(rows), ptr(mean), ptr(rstd), ptr(w), ptr(dx_in), ptr(dx_out),
                                  c_long(dx_out.stride(0)), ptr(dxb), c_long(dxb.stride(0) if dxb is not None else 0),
-                                 ptr(dw), ptr(db), c_int(M), c_int(D), stream()), "ce_layernorm_bwd")
+                                 ptr(dw), ptr(db), ptr(dxsum), c_int(M), c_int(D), stream()), "ce_layernorm_bwd")
     return dx_out
 
 

@@ -65,6 +65,9 @@ int ce_gemm_nt(const void* A, long lda, const void* B, long ldb, int M, int N, i
  * caller zeroes `out` once per step).  splits<=0 picks the M split that fills the chip. */
 int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out, long ldo,
                int splits, void* stream);
+/* same, plus the fused bias gradient bias_grad[n] (f32 [Nn], nullable) += sum_m P[m,n] */
+int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out, long ldo,
+                    float* bias_grad, int splits, void* stream);
 
 /* y = LayerNorm(x[rows[r]] or x[r]) over D columns, fp32 statistics (eps inside the sqrt).
  * y is bf16 (out_f32=0: the next GEMM's operand) or fp32 (ln_pre: the residual stream).
@@ -73,10 +76,12 @@ int ce_layernorm_fwd(const float* x, long ldx, const int* rows, const float* w, 
                      int out_f32, float* mean, float* rstd, int M, int D, float eps, void* stream);
 
 /* dx_out[dst] = (dx_in ? dx_in[dst] : 0) + dLN(dy[r]); dst = rows ? rows[r] : r; dxb = bf16 copy
- * (nullable); dw/db (f32 [D]) accumulate atomically (caller zeroes once per step). */
+ * (nullable); dw/db (f32 [D]) accumulate atomically (caller zeroes once per step); dxsum (f32 [D],
+ * nullable) += column sums of dx_out = the bias gradient of the Linear that produced this stream. */
 int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const float* x, long ldx, const int* rows,
                      const float* mean, const float* rstd, const float* w, const float* dx_in, float* dx_out,
-                     long lddx, void* dxb, long lddxb, float* dw, float* db, int M, int D, void* stream);
+                     long lddx, void* dxb, long lddxb, float* dw, float* db, float* dxsum, int M, int D,
+                     void* stream);
 
 /* Self-attention core on the packed in-projection output qkv[B*L, 3*H*64] (bf16; q | k | v column
  * blocks, head h at columns h*64): o[B*L, H*64] = softmax(q k^T / 8 + causal?) v, lse[B*H*L] (f32)

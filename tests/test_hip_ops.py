@@ -168,3 +168,20 @@ def test_attention_fwd_bwd(B, L, H, causal):
     g = qkv_r.grad
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert _report(f"attn {name} L={L}", dqkv[:, sl].float().cpu(), g[:, sl])[1] < 2e-2
+
+
+@pytest.mark.parametrize("M,Nn,Kk", [(1000, 768, 512), (616, 512, 2048), (50, 64, 72), (12800, 768, 768), (77, 1536, 512)])
+def test_gemm_tn_fused_bias_grad(M, Nn, Kk):
+    from ctypes import c_int, c_long
+    from clip_event_amd._lib import check, lib, ptr, stream
+    rng = np.random.default_rng(M + 3 * Nn + Kk)
+    p = _randn(rng, M, Nn).to(torch.bfloat16)
+    q = _randn(rng, M, Kk, scale=M ** -0.5).to(torch.bfloat16)
+    P, Q = p.to(DEV), q.to(DEV)
+    out = torch.zeros(Nn, Kk, device=DEV)
+    bg = torch.zeros(Nn, device=DEV)
+    check(lib().ce_gemm_tn_bias(ptr(P), c_long(Nn), ptr(Q), c_long(Kk), c_int(M), c_int(Nn), c_int(Kk), ptr(out), c_long(Kk),
+                                ptr(bg), c_int(0), stream()), "ce_gemm_tn_bias")
+    torch.cuda.synchronize()
+    assert _report(f"tn+bias {M}x{Nn}x{Kk} dW", out.cpu(), p.float().t() @ q.float())[1] < 2e-5
+    assert _report("tn+bias db", bg.cpu(), p.float().sum(0))[1] < 2e-5

@@ -37,6 +37,11 @@ def main():
         g = torch.zeros(N, K, device=DEV)
         t = timeit(lambda: ops.gemm_tn(dy, a, g))
         print(f"tn  {name:8s} M={M} N={N} K={K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+        from ctypes import c_int, c_long
+        from clip_event_amd._lib import check, lib, ptr, stream
+        bg = torch.zeros(N, device=DEV)
+        t = timeit(lambda: check(lib().ce_gemm_tn_bias(ptr(dy), c_long(N), ptr(a), c_long(K), c_int(M), c_int(N), c_int(K), ptr(g), c_long(K), ptr(bg), c_int(0), stream()), "tnb"))
+        print(f"tnb {name:8s} M={M} N={N} K={K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
     for M, D in [(12800, 768), (19712, 512)]:
         x = torch.randn(M, D, device=DEV)
         w = torch.ones(D, device=DEV); b = torch.zeros(D, device=DEV)
