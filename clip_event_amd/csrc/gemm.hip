@@ -194,16 +194,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
 // lane-linear, so the XOR swizzle (chunk ^= row&7) is applied to the per-lane SOURCE address
 // and again on the fragment reads.  One barrier per K-tile, next tile in flight during the MFMAs.
 // ------------------------------------------------------------------------------------------
-constexpr int N2_BM = 256, N2_BN = 256, N2_BK = 64;
-constexpr int N2_TILE_BYTES = N2_BM * N2_BK * 2;            // 32 KiB per operand
-constexpr int N2_STAGE_BYTES = 2 * N2_TILE_BYTES;           // 64 KiB
-constexpr int N2_LDS_BYTES = 8 * 64 * 272;                 // 136 KiB: 2 stages (128 KiB) or 8 epilogue slices of 17 KiB
+// BM = 32*TM rows (TM = m-tiles of 16 per wave): TM=8 -> 256x256, TM=5 -> 160x256.  The smaller tile
+// exists for wave quantisation: N = width GEMMs have only 2-3 tile columns, and 160-row tiles give
+// 240-248 workgroups for the 256 CUs where 256-row tiles give 150.
+constexpr int N2_BN = 256, N2_BK = 64;
+constexpr int N2_BTILE_BYTES = N2_BN * N2_BK * 2;           // 32 KiB
+constexpr int N2_LDS_BYTES = 8 * 64 * 272;                 // 136 KiB: 2 stages (<=128 KiB) or 8 epilogue slices of 17 KiB
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-template <int EPI>
+template <int EPI, int TM>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
+    constexpr int N2_BM = 32 * TM;
+    constexpr int N2_TILE_BYTES = N2_BM * N2_BK * 2;            // A tile
+    constexpr int N2_STAGE_BYTES = N2_TILE_BYTES + N2_BTILE_BYTES;
+    constexpr int A_INSTR = N2_BM / 8;                          // 1-KiB DMA instructions per A tile
+    constexpr int A_PER_WAVE = (A_INSTR + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,29 +225,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     // lane l lands at LDS (row r = l>>3, position pos = l&7) and therefore fetches chunk pos ^ (r&7).
     const int s_r = lane >> 3, s_pos = lane & 7;
     const int s_chunk = s_pos ^ s_r;
-    const bf16_t* gA[4];
+    const bf16_t* gA[A_PER_WAVE];
     const bf16_t* gB[4];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {    // A instruction index = wave + 8*i (wave-uniform bound check below)
+        const int row = (wave + 8 * i) * 8 + s_r;
+        const int ra = min(m0 + row, p.M - 1);                                  // clamp: rows past the edge are never stored
+        gA[i] = p.A + (long)ra * p.lda + s_chunk * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + s_r;
-        const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);   // clamp: rows past the edge are never stored
-        gA[i] = p.A + (long)ra * p.lda + s_chunk * 8;
+        const int rb = min(n0 + row, p.N - 1);
         gB[i] = p.B + (long)rb * p.ldb + s_chunk * 8;
     }
     auto stage = [&](int st, int kt) {
-        char* sa = smem + st * N2_STAGE_BYTES + wave * 4096;
-        char* sb = sa + N2_TILE_BYTES;
+        char* sa = smem + st * N2_STAGE_BYTES;
+        char* sb = sa + N2_TILE_BYTES + wave * 4096;
         const int koff = kt * N2_BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t*)(gA[i] + koff), (lptr_t*)(sa + i * 1024), 16, 0, 0);
+        for (int i = 0; i < A_PER_WAVE; ++i)
+            if (wave + 8 * i < A_INSTR)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(gA[i] + koff), (lptr_t*)(sa + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(gB[i] + koff), (lptr_t*)(sb + i * 1024), 16, 0, 0);
-        }
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
 
     const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
-    const int fa_base = (wm * 128 + f_row) * 128;
+    const int fa_base = (wm * (TM * 16) + f_row) * 128;
     const int fb_base = N2_TILE_BYTES + (wn * 64 + f_row) * 128;
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -263,17 +277,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh) {
+            for (int mh = 0; mh * 4 < TM; ++mh) {
+                constexpr int dummy = 0;
+                (void)dummy;
                 bf16x8 af[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + (mh * 4 + t) * 2048 + coff);
+                    if (mh * 4 + t < TM)
+                        af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + (mh * 4 + t) * 2048 + coff);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
+                    if (mh * 4 + t < TM) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mh * 4 + t][nt] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[mh * 4 + t][nt], 0, 0, 0);
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mh * 4 + t][nt] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[mh * 4 + t][nt], 0, 0, 0);
+                    }
             }
         }
         __syncthreads();
@@ -296,16 +315,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         }
     }
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {
+    for (int mh = 0; mh * 4 < TM; ++mh) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
+            if (mh * 4 + t < TM) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<f32x4*>(ebuf + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) =
-                    acc[mh * 4 + t][nt];
-        const int gm0 = m0 + wm * 128 + mh * 64 + e_r;
+                for (int nt = 0; nt < 4; ++nt)
+                    *reinterpret_cast<f32x4*>(ebuf + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) =
+                        acc[mh * 4 + t][nt];
+            }
+        const int gm0 = m0 + wm * (TM * 16) + mh * 64 + e_r;
+        constexpr int ITS_FULL = 8;
+        const int its = (TM - mh * 4 >= 4) ? ITS_FULL : (TM - mh * 4) * 2;   // 8 rows per iteration
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+            if (it >= its) break;
             const int m = gm0 + it * 8;
             f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
             f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
@@ -660,13 +684,24 @@ int nt_variant() {   // CE_GEMM_NT=128|256 forces a tile; default: pick per shap
     return v;
 }
 
+int force_tm() {   // CE_GEMM_TM=8|5 forces the 256-column kernel's tile height
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CE_GEMM_TM");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int EPI>
 int launch_nt(NTArgs a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
         attr_set = true;
     }
@@ -676,9 +711,18 @@ int launch_nt(NTArgs a, hipStream_t stream) {
     const bool can256 = (a.K % N2_BK == 0) && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo2 % 8 == 0 && a.ldaux % 8 == 0;
     const bool want256 = force == 256 || (force == 0 && a.M >= 1024 && a.N >= 256);
     if (can256 && want256) {
-        a.tiles_m = ce_div_up(a.M, N2_BM);
         a.tiles_n = ce_div_up(a.N, N2_BN);
-        hipLaunchKernelGGL(gemm_nt256_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+        // pick the tile height by wave quantisation: cost ~ (rounds over 256 CUs) x (rows per tile)
+        const long t8 = (long)ce_div_up(a.M, 256) * a.tiles_n, t5 = (long)ce_div_up(a.M, 160) * a.tiles_n;
+        const long c8 = ((t8 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 160;
+        const bool use5 = force_tm() == 5 || (force_tm() == 0 && c5 < c8);
+        if (use5) {
+            a.tiles_m = ce_div_up(a.M, 160);
+            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+        } else {
+            a.tiles_m = ce_div_up(a.M, 256);
+            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 8>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+        }
     } else {
         hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
     }
