@@ -525,8 +525,17 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool BIAS>
-__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __restrict__ bias_grad) {
+// up to 4 weight-gradient problems that share the contraction length M (one residual block's four
+// Linear layers) in ONE launch: the tile lists are concatenated, so the launch has enough tiles to fill the
+// chip with few (usually 1-2) M splits -> 4x fewer atomic bytes and 4x longer-lived workgroups than four
+// separate launches.
+struct TNGroup {
+    int count, splits, m_per_split, M;
+    int tile_end[4];
+    TNArgs prob[4];
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -534,12 +543,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __res
     const int wn = wave >> 1, wk = wave & 1;
 
     int bid = blockIdx.x;
-    const int split = bid % p.splits;
-    bid /= p.splits;
+    const int split = bid % grp.splits;
+    bid /= grp.splits;
+    int pi = 0;
+    while (pi + 1 < grp.count && bid >= grp.tile_end[pi]) ++pi;   // block-uniform
+    if (pi > 0) bid -= grp.tile_end[pi - 1];
+    const TNArgs& p = grp.prob[pi];
     const int tk = bid % p.tiles_k, tn = bid / p.tiles_k;
     const int n0 = tn * TN_BN, k0 = tk * TN_BK;
-    const int ms = split * p.m_per_split;
-    const int me = min(p.M, ms + p.m_per_split);
+    const int ms = split * grp.m_per_split;
+    const int me = min(grp.M, ms + grp.m_per_split);
     if (ms >= me) return;  // uniform per block
     const int rows = me - ms;
 
@@ -557,11 +570,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __res
         vP[j] = (uint32_t)(row * p.ldp * 2 + (n0 + s_chunk * 8) * 2);
         vQ[j] = (uint32_t)(row * p.ldq * 2 + (k0 + s_chunk * 8) * 2);
     }
+    const long ldp = p.ldp, ldq = p.ldq;
     auto stage = [&](int st, int mt) {
         char* sp = smem + st * T2_STAGE_BYTES + wave * 4096;
         char* sq = sp + T2_TILE_BYTES;
-        const uint32_t mbP = (uint32_t)((long)mt * TN_BM * p.ldp * 2);
-        const uint32_t mbQ = (uint32_t)((long)mt * TN_BM * p.ldq * 2);
+        const uint32_t mbP = (uint32_t)((long)mt * TN_BM * ldp * 2);
+        const uint32_t mbQ = (uint32_t)((long)mt * TN_BM * ldq * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (lptr_t*)(sp + j * 1024), 16, vP[j] + mbP, 0, 0, 0);
@@ -570,18 +584,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __res
     };
 
     f32x16 acc[2][2];
-    f32x16 accb[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
-        accb[0][r] = 0.f; accb[1][r] = 0.f;
     }
-    // bias-gradient work is spread evenly: of every (2*tiles_k) contraction steps of a (tn, split) column,
-    // the wave (tk, wk) takes one, so no workgroup carries more MFMAs than the others
-    const int bias_mod = 2 * p.tiles_k, bias_me = 2 * tk + wk;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     // transposed-read addresses (see v1) on 256-byte rows with the chunk swizzle
     const int g = lane >> 4, li = lane & 15;
@@ -598,13 +604,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __res
     const int nmt = (rows + TN_BM - 1) / TN_BM;
     stage(0, 0);
     __syncthreads();
-    int bturn = bias_me;   // this wave takes the bias MFMAs of every bias_mod-th m-tile (wave-uniform countdown)
     for (int mt = 0; mt < nmt; ++mt) {
         const int cur = mt & 1;
         if (mt + 1 < nmt) stage(cur ^ 1, mt + 1);
         const char* st = smem + cur * T2_STAGE_BYTES;
-        const bool bias_now = BIAS && (bturn == 0);
-        bturn = (bturn == 0) ? bias_mod - 1 : bturn - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 pf[2], qf[2];
@@ -618,10 +621,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __res
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
                     acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
-            if (bias_now) {
-                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[0], ones, accb[0], 0, 0, 0);
-                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[1], ones, accb[1], 0, 0, 0);
-            }
         }
         __syncthreads();
     }
@@ -640,15 +639,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNArgs p, float* __res
                 if (n < p.Nn) atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
             }
         }
-    if (BIAS && (lane & 31) == 0) {   // every column of accb holds the same row sums: take column 0
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
-                if (n < p.Nn) atomicAdd(bias_grad + n, accb[nt][r]);
-            }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,52 +766,73 @@ extern "C" int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int 
 
 extern "C" int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out,
                                long ldo, float* bias_grad, int splits, void* stream) {
-    CE_CHECK_ARG(M > 0 && Nn > 0 && Kk > 0, "ce_gemm_tn: empty problem");
-    CE_CHECK_ARG(Nn % 8 == 0 && Kk % 8 == 0 && ldp % 8 == 0 && ldq % 8 == 0, "ce_gemm_tn: Nn,Kk,ldp,ldq must be multiples of 8");
-    CE_CHECK_ARG(ldp >= Nn && ldq >= Kk && ldo >= Kk, "ce_gemm_tn: leading dimension smaller than the row");
-    TNArgs a;
-    a.P = (const bf16_t*)P; a.ldp = ldp; a.Q = (const bf16_t*)Q; a.ldq = ldq; a.out = out; a.ldo = ldo;
-    a.M = M; a.Nn = Nn; a.Kk = Kk;
-    a.tiles_n = ce_div_up(Nn, TN_BN); a.tiles_k = ce_div_up(Kk, TN_BK);
-    const int m_tiles = ce_div_up(M, TN_BM);
-    if (splits <= 0) {  // one resident round: at most 2 workgroups per CU (512 slots), never a ragged second round
-        const int tiles = a.tiles_n * a.tiles_k;
-        splits = 512 / tiles;
-    }
-    if (splits > m_tiles) splits = m_tiles;
-    if (splits < 1) splits = 1;
-    a.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
-    a.splits = ce_div_up(M, a.m_per_split);
-    CE_CHECK_ARG((long)a.m_per_split * (ldp > ldq ? ldp : ldq) * 2 < (1L << 32), "ce_gemm_tn: split exceeds 4 GiB");
+    const void* Ps[1] = {P};
+    const void* Qs[1] = {Q};
+    float* outs[1] = {out};
+    int rc = ce_gemm_tn_grouped(1, Ps, &ldp, Qs, &ldq, M, &Nn, &Kk, outs, &ldo, splits, stream);
+    if (rc != 0) return rc;
+    if (bias_grad) return ce_colsum_bf16(P, ldp, bias_grad, M, Nn, stream);
+    return 0;
+}
+
+extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const void* const* Q,
+                                  const long* ldq, int M, const int* Nn, const int* Kk, float* const* out,
+                                  const long* ldo, int splits, void* stream) {
+    CE_CHECK_ARG(count >= 1 && count <= 4 && M > 0, "ce_gemm_tn_grouped: 1..4 problems, M > 0");
     static bool attr_set = false;
-    static int variant = 2;   // CE_GEMM_TN=1 forces the register-staged v1 kernel
+    static int variant = 2;   // CE_GEMM_TN=1 forces the register-staged v1 kernel (one launch per problem)
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TN_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            T2_LDS_BYTES);
         const char* e = getenv("CE_GEMM_TN");
         if (e) variant = atoi(e);
         attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(a.tiles_n * a.tiles_k * a.splits);
+    TNGroup g;
+    g.count = count;
+    g.M = M;
+    int tiles = 0;
+    double flops = 0.0, bytes = 0.0;
+    long ldmax = 0;
+    for (int i = 0; i < count; ++i) {
+        CE_CHECK_ARG(Nn[i] > 0 && Kk[i] > 0, "ce_gemm_tn: empty problem");
+        CE_CHECK_ARG(Nn[i] % 8 == 0 && Kk[i] % 8 == 0 && ldp[i] % 8 == 0 && ldq[i] % 8 == 0,
+                     "ce_gemm_tn: Nn,Kk,ldp,ldq must be multiples of 8");
+        CE_CHECK_ARG(ldp[i] >= Nn[i] && ldq[i] >= Kk[i] && ldo[i] >= Kk[i], "ce_gemm_tn: leading dimension smaller than the row");
+        TNArgs& a = g.prob[i];
+        a.P = (const bf16_t*)P[i]; a.ldp = ldp[i]; a.Q = (const bf16_t*)Q[i]; a.ldq = ldq[i];
+        a.out = out[i]; a.ldo = ldo[i]; a.M = M; a.Nn = Nn[i]; a.Kk = Kk[i];
+        a.tiles_n = ce_div_up(Nn[i], TN_BN); a.tiles_k = ce_div_up(Kk[i], TN_BK);
+        tiles += a.tiles_n * a.tiles_k;
+        g.tile_end[i] = tiles;
+        flops += 2.0 * M * Nn[i] * Kk[i];
+        bytes += 2.0 * ((double)M * Nn[i] + (double)M * Kk[i]) + 8.0 * Nn[i] * Kk[i];
+        if (ldp[i] > ldmax) ldmax = ldp[i];
+        if (ldq[i] > ldmax) ldmax = ldq[i];
+    }
+    for (int i = count; i < 4; ++i) g.tile_end[i] = tiles;
+    const int m_tiles = ce_div_up(M, TN_BM);
+    if (splits <= 0) splits = 512 / tiles;   // one resident round: at most 2 workgroups per CU, never a ragged second round
+    if (splits > m_tiles) splits = m_tiles;
+    if (splits < 1) splits = 1;
+    g.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
+    g.splits = ce_div_up(M, g.m_per_split);
+    CE_CHECK_ARG((long)g.m_per_split * ldmax * 2 < (1L << 32), "ce_gemm_tn: split exceeds 4 GiB");
     if (variant == 1) {
-        {
-            CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * Nn * Kk, 2.0 * ((double)M * Nn + (double)M * Kk) + 8.0 * Nn * Kk, s);
-            hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), TN_LDS_BYTES, s, a);
+        for (int i = 0; i < count; ++i) {
+            TNArgs a = g.prob[i];
+            a.splits = g.splits; a.m_per_split = g.m_per_split;
+            CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * a.Nn * a.Kk, 0.0, s);
+            hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k * a.splits), dim3(256), TN_LDS_BYTES, s, a);
         }
         CE_LAUNCH_CHECK();
-        if (bias_grad) return ce_colsum_bf16(P, ldp, bias_grad, M, Nn, stream);
         return 0;
     }
-    CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * Nn * Kk, 2.0 * ((double)M * Nn + (double)M * Kk) + 8.0 * Nn * Kk, s);
-    if (bias_grad)
-        hipLaunchKernelGGL(gemm_tn2_kernel<true>, grid, dim3(256), T2_LDS_BYTES, s, a, bias_grad);
-    else
-        hipLaunchKernelGGL(gemm_tn2_kernel<false>, grid, dim3(256), T2_LDS_BYTES, s, a, bias_grad);
+    CeProfScope prof(CE_PROF_GEMM_TN, flops, bytes, s);
+    hipLaunchKernelGGL(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(256), T2_LDS_BYTES, s, g);
     CE_LAUNCH_CHECK();
     return 0;
 }

@@ -36,7 +36,7 @@ struct BlockStash {
 struct Layout {
     static constexpr int MAX_LAYERS = 64;
     BlockStash blk[MAX_LAYERS];
-    bf16_t *dxb, *dh, *da, *dqkv, *d_o;
+    bf16_t *dxb, *dxb2, *dh, *da, *dqkv, *d_o;
     size_t bytes;
 };
 
@@ -60,6 +60,7 @@ void carve(const ce_tower_desc* d, int batch, void* ws, Layout& L) {
         s.lse = c.take<float>((size_t)batch * d->heads * d->tokens);
     }
     L.dxb = c.take<bf16_t>(M * w);
+    L.dxb2 = c.take<bf16_t>(M * w);
     L.dh = c.take<bf16_t>(M * w);
     L.da = c.take<bf16_t>(M * 4 * w);
     L.dqkv = c.take<bf16_t>(M * 3 * w);
@@ -126,38 +127,51 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
     Layout L;
     carve(d, batch, workspace, L);
     const int M = batch * d->tokens, w = d->width;
-    TRY(ce_cast_bf16(dx, L.dxb, (long)M * w, stream));
+    // dxb_a: bf16 gradient at the block output (operand of mlp.c_proj's dgrad/wgrad);
+    // dxb_b: bf16 gradient at x_mid (operand of attn.out_proj's dgrad/wgrad).  Both stay alive until the
+    // block's four weight gradients run as ONE grouped launch after the last dgrad.
+    bf16_t* dxb_a = L.dxb;
+    bf16_t* dxb_b = L.dxb2;
+    TRY(ce_cast_bf16(dx, dxb_a, (long)M * w, stream));
     for (int l = d->layers - 1; l >= 0; --l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         // ---- mlp.c_proj : x_out = x_mid + g Wp^T + bp ----
-        TRY(ce_gemm_nt(L.dxb, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.da, 4 * w, nullptr,
+        TRY(ce_gemm_nt(dxb_a, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.da, 4 * w, nullptr,
                        0, s.a, 4 * w, stream));                                   // da = (dx Wp) * gelu'(a)
-        TRY(ce_gemm_tn(L.dxb, w, s.g, 4 * w, M, w, 4 * w, p.g_w_proj, 4 * w, 0, stream));
-        if (l == d->layers - 1) TRY(ce_colsum_bf16(L.dxb, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
+        if (l == d->layers - 1) TRY(ce_colsum_bf16(dxb_a, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
         // ---- mlp.c_fc : a = h2 Wf^T + bf ----
         TRY(ce_gemm_nt(L.da, 4 * w, p.wt_fc, 4 * w, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh2 = da Wf
-        TRY(ce_gemm_tn(L.da, 4 * w, s.h2, w, M, 4 * w, w, p.g_w_fc, w, 0, stream));
         TRY(ce_colsum_bf16(L.da, 4 * w, p.g_b_fc, M, 4 * w, stream));
-        // ---- ln_2 (+ residual) ----
-        TRY(ce_layernorm_bwd(L.dh, w, 0, s.x_mid, w, nullptr, s.mean2, s.rstd2, p.ln2_w, dx, dx, w, L.dxb, w, p.g_ln2_w,
+        // ---- ln_2 (+ residual); also the column sums of dx = attn.out_proj bias gradient ----
+        TRY(ce_layernorm_bwd(L.dh, w, 0, s.x_mid, w, nullptr, s.mean2, s.rstd2, p.ln2_w, dx, dx, w, dxb_b, w, p.g_ln2_w,
                              p.g_ln2_b, p.g_b_out, M, w, stream));
         // ---- attn.out_proj : x_mid = x_in + o Wo^T + bo ----
-        TRY(ce_gemm_nt(L.dxb, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
+        TRY(ce_gemm_nt(dxb_b, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
                        stream));                                                  // d_o = dx Wo
-        TRY(ce_gemm_tn(L.dxb, w, s.o, w, M, w, w, p.g_w_out, w, 0, stream));          // bias grad: fused in ln_2's backward
         // ---- attention core ----
         TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
                              stream));
         // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
         TRY(ce_gemm_nt(L.dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh1 = dqkv Wqkv
-        TRY(ce_gemm_tn(L.dqkv, 3 * w, s.h1, w, M, 3 * w, w, p.g_w_qkv, w, 0, stream));
         TRY(ce_colsum_bf16(L.dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
-        // ---- ln_1 (+ residual) ----
-        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb, w, p.g_ln1_w,
+        // ---- the four weight gradients of this block, one launch ----
+        {
+            const void* P[4] = {dxb_a, L.da, dxb_b, L.dqkv};
+            const long ldp[4] = {w, 4L * w, w, 3L * w};
+            const void* Q[4] = {s.g, s.h2, s.o, s.h1};
+            const long ldq[4] = {4L * w, w, w, w};
+            const int Nn[4] = {w, 4 * w, w, 3 * w};
+            const int Kk[4] = {4 * w, w, w, w};
+            float* out[4] = {p.g_w_proj, p.g_w_fc, p.g_w_out, p.g_w_qkv};
+            const long ldo[4] = {4L * w, w, w, w};
+            TRY(ce_gemm_tn_grouped(4, P, ldp, Q, ldq, M, Nn, Kk, out, ldo, 0, stream));
+        }
+        // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient ----
+        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, dxb_a, w, p.g_ln1_w,
                              p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
     }
     return 0;

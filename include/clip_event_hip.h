@@ -65,9 +65,12 @@ int ce_gemm_nt(const void* A, long lda, const void* B, long ldb, int M, int N, i
  * caller zeroes `out` once per step).  splits<=0 picks the M split that fills the chip. */
 int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out, long ldo,
                int splits, void* stream);
-/* same, plus the fused bias gradient bias_grad[n] (f32 [Nn], nullable) += sum_m P[m,n] */
+/* same, plus the bias gradient bias_grad[n] (f32 [Nn], nullable) += sum_m P[m,n] */
 int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out, long ldo,
                     float* bias_grad, int splits, void* stream);
+/* 1..4 weight-gradient problems sharing M in one launch (the four Linear layers of a residual block) */
+int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const void* const* Q, const long* ldq, int M,
+                       const int* Nn, const int* Kk, float* const* out, const long* ldo, int splits, void* stream);
 
 /* y = LayerNorm(x[rows[r]] or x[r]) over D columns, fp32 statistics (eps inside the sqrt).
  * y is bf16 (out_f32=0: the next GEMM's operand) or fp32 (ln_pre: the residual stream).
