@@ -525,6 +525,26 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// LDS-DMA through inline asm: hipcc does not track asm memory operations, so it cannot serialise the DMA
+// against the fragment reads of the OTHER stage (it did, with the builtin, once the kernel grew an outer
+// loop: an s_waitcnt vmcnt(0) in front of every m-tile's first ds_read).  The kernel waits for the DMA
+// itself (vmcnt(0) ahead of the barrier that publishes a stage).  M0 (the LDS destination) is saved and
+// restored inside the statement; the leading s_nop covers SGPR-write -> VMEM-read wait states.
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void dma16_bounds(u32x4 rsrc, uint32_t lds_dst, uint32_t voff) {
+    uint32_t keep;
+    asm volatile(
+        "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_dst), "s"(rsrc)
+        : "memory");
+}
+
 // up to 4 weight-gradient problems that share the contraction length M (one residual block's four
 // Linear layers) in ONE launch: the tile lists are concatenated, so the launch has enough tiles to fill the
 // chip with few (usually 1-2) M splits -> 4x fewer atomic bytes and 4x longer-lived workgroups than four
@@ -542,54 +562,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
 
-    int bid = blockIdx.x;
-    const int split = bid % grp.splits;
-    bid /= grp.splits;
-    int pi = 0;
-    while (pi + 1 < grp.count && bid >= grp.tile_end[pi]) ++pi;   // block-uniform
-    if (pi > 0) bid -= grp.tile_end[pi - 1];
-    const TNArgs& p = grp.prob[pi];
-    const int tk = bid % p.tiles_k, tn = bid / p.tiles_k;
-    const int n0 = tn * TN_BN, k0 = tk * TN_BK;
-    const int ms = split * grp.m_per_split;
-    const int me = min(grp.M, ms + grp.m_per_split);
-    if (ms >= me) return;  // uniform per block
-    const int rows = me - ms;
-
-    __amdgpu_buffer_rsrc_t rP = make_rsrc(p.P + (long)ms * p.ldp, (uint32_t)((long)rows * p.ldp * 2));
-    __amdgpu_buffer_rsrc_t rQ = make_rsrc(p.Q + (long)ms * p.ldq, (uint32_t)((long)rows * p.ldq * 2));
-
-    // DMA map: instruction (wave*4 + j) fills rows (wave*4+j)*4 .. +3; lane -> row r = lane>>4, position lane&15,
-    // source chunk = position ^ (r<<2)
+    // grid = (tiles of all problems) x splits; split is the fastest index so the workgroups that run together
+    // sweep the SAME m-range of different tiles and share their P / Q panels in L2.  (A stream-K style split of
+    // (tile, m-tile) units balances the grid perfectly but de-synchronises the m-ranges; measured 40 % slower.)
+    const int m_tiles = (grp.M + TN_BM - 1) / TN_BM;
+    const int mps = grp.m_per_split / TN_BM;             // m-tiles per split
+    // lane-constant pieces of the DMA and transposed-read maps
     const int s_r = lane >> 4;
     const int s_chunk = (lane & 15) ^ (s_r << 2);
-    uint32_t vP[4], vQ[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 4 + s_r;
-        vP[j] = (uint32_t)(row * p.ldp * 2 + (n0 + s_chunk * 8) * 2);
-        vQ[j] = (uint32_t)(row * p.ldq * 2 + (k0 + s_chunk * 8) * 2);
-    }
-    const long ldp = p.ldp, ldq = p.ldq;
-    auto stage = [&](int st, int mt) {
-        char* sp = smem + st * T2_STAGE_BYTES + wave * 4096;
-        char* sq = sp + T2_TILE_BYTES;
-        const uint32_t mbP = (uint32_t)((long)mt * TN_BM * ldp * 2);
-        const uint32_t mbQ = (uint32_t)((long)mt * TN_BM * ldq * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (lptr_t*)(sp + j * 1024), 16, vP[j] + mbP, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rQ, (lptr_t*)(sq + j * 1024), 16, vQ[j] + mbQ, 0, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
-    }
-
-    // transposed-read addresses (see v1) on 256-byte rows with the chunk swizzle
     const int g = lane >> 4, li = lane & 15;
     const int t_row = 8 * (g >> 1) + (li >> 2);
     const int t_sw = (li >> 2) << 2;
@@ -601,44 +581,92 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
         offQ[t] = T2_TILE_BYTES + t_row * 256 + (((wk * 8 + t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
     }
 
-    const int nmt = (rows + TN_BM - 1) / TN_BM;
-    stage(0, 0);
-    __syncthreads();
-    for (int mt = 0; mt < nmt; ++mt) {
-        const int cur = mt & 1;
-        if (mt + 1 < nmt) stage(cur ^ 1, mt + 1);
-        const char* st = smem + cur * T2_STAGE_BYTES;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 pf[2], qf[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                pf[t] = tr_frag2(st + offP[t] + s * 16 * 256);
-                qf[t] = tr_frag2(st + offQ[t] + s * 16 * 256);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
-        }
-        __syncthreads();
-    }
+    {
+        int tile = blockIdx.x / grp.splits;
+        const int mt0 = (blockIdx.x - tile * grp.splits) * mps;
+        const int mt1 = min(m_tiles, mt0 + mps);
+        if (mt0 >= mt1) return;  // uniform per block
+        int pi = 0;
+        while (pi + 1 < grp.count && tile >= grp.tile_end[pi]) ++pi;   // block-uniform
+        if (pi > 0) tile -= grp.tile_end[pi - 1];
+        const TNArgs& p = grp.prob[pi];
+        const int tk = tile % p.tiles_k, tn = tile / p.tiles_k;
+        const int n0 = tn * TN_BN, k0 = tk * TN_BK;
+        const int ms = mt0 * TN_BM;
+        const int rows = min(grp.M, mt1 * TN_BM) - ms;
+        const long ldp = p.ldp, ldq = p.ldq;
 
-    const int ek = k0 + wk * 64 + (lane & 31);
-    const int en = n0 + wn * 64 + 4 * (lane >> 5);
+        const u32x4 rP = make_rsrc_words(p.P + (long)ms * ldp, (uint32_t)((long)rows * ldp * 2));
+        const u32x4 rQ = make_rsrc_words(p.Q + (long)ms * ldq, (uint32_t)((long)rows * ldq * 2));
+        // DMA map: instruction (wave*4 + j) fills rows (wave*4+j)*4 .. +3; lane -> row r = lane>>4, position
+        // lane&15, source chunk = position ^ (r<<2)
+        uint32_t vP[4], vQ[4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int k = ek + kt * 32;
-            if (k >= p.Kk) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
-                if (n < p.Nn) atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 4 + s_r;
+            vP[j] = (uint32_t)(row * ldp * 2 + (n0 + s_chunk * 8) * 2);
+            vQ[j] = (uint32_t)(row * ldq * 2 + (k0 + s_chunk * 8) * 2);
         }
+        const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + wave * 4096;
+        auto stage = [&](int st, int mt) {
+            const uint32_t dp = lds0 + st * T2_STAGE_BYTES;
+            const uint32_t dq = dp + T2_TILE_BYTES;
+            const uint32_t mbP = (uint32_t)((long)mt * TN_BM * ldp * 2);
+            const uint32_t mbQ = (uint32_t)((long)mt * TN_BM * ldq * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dma16_bounds(rP, dp + j * 1024, vP[j] + mbP);
+                dma16_bounds(rQ, dq + j * 1024, vQ[j] + mbQ);
+            }
+        };
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+        }
+
+        const int nmt = mt1 - mt0;
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int mt = 0; mt < nmt; ++mt) {
+            const int cur = mt & 1;
+            if (mt + 1 < nmt) stage(cur ^ 1, mt + 1);
+            const char* st = smem + cur * T2_STAGE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 pf[2], qf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    pf[t] = tr_frag2(st + offP[t] + s * 16 * 256);
+                    qf[t] = tr_frag2(st + offQ[t] + s * 16 * 256);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (this wave's DMA)
+            __syncthreads();
+        }
+
+        const int ek = k0 + wk * 64 + (lane & 31);
+        const int en = n0 + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int k = ek + kt * 32;
+                if (k >= p.Kk) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+                    if (n < p.Nn) atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
+                }
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -815,13 +843,13 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
     }
     for (int i = count; i < 4; ++i) g.tile_end[i] = tiles;
     const int m_tiles = ce_div_up(M, TN_BM);
-    if (splits <= 0) splits = 512 / tiles;   // one resident round: at most 2 workgroups per CU, never a ragged second round
-    if (splits > m_tiles) splits = m_tiles;
-    if (splits < 1) splits = 1;
-    g.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
-    g.splits = ce_div_up(M, g.m_per_split);
-    CE_CHECK_ARG((long)g.m_per_split * ldmax * 2 < (1L << 32), "ce_gemm_tn: split exceeds 4 GiB");
+    CE_CHECK_ARG((long)M * ldmax * 2 < (1L << 32), "ce_gemm_tn: operand exceeds 4 GiB");
     if (variant == 1) {
+        if (splits <= 0) splits = 512 / tiles;
+        if (splits > m_tiles) splits = m_tiles;
+        if (splits < 1) splits = 1;
+        g.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
+        g.splits = ce_div_up(M, g.m_per_split);
         for (int i = 0; i < count; ++i) {
             TNArgs a = g.prob[i];
             a.splits = g.splits; a.m_per_split = g.m_per_split;
@@ -831,8 +859,14 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         CE_LAUNCH_CHECK();
         return 0;
     }
+    // v2: one resident round (at most 2 workgroups per CU = 512 slots), never a ragged second round
+    if (splits <= 0) splits = 512 / tiles;
+    if (splits > m_tiles) splits = m_tiles;
+    if (splits < 1) splits = 1;
+    g.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
+    g.splits = ce_div_up(M, g.m_per_split);
     CeProfScope prof(CE_PROF_GEMM_TN, flops, bytes, s);
-    hipLaunchKernelGGL(gemm_tn2_kernel, dim3(tiles * g.splits), dim3(256), T2_LDS_BYTES, s, g);
+    hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)(tiles * g.splits)), dim3(256), T2_LDS_BYTES, s, g);
     CE_LAUNCH_CHECK();
     return 0;
 }
