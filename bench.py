@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU image batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="run both towers on one stream (the default overlaps them on two)")
     return ap.parse_args()
 
 
@@ -117,6 +119,7 @@ def main():
 
     B = args.batch
     model = build_model(O.init_params(O.VIT_B32, 0)).to(dev)       # same weights on every rank
+    model.tower_streams = not args.single_stream
     crit = CriterionContrastive("ce")
     opt = FusedAdam(model, lr=1e-6, weight_decay=0.0, max_norm=1.0)    # README.md:189-191 defaults
     sync = D.GradSync(model) if W > 1 else None
@@ -153,6 +156,12 @@ def main():
         # instrumented pass: HIP events on the launch stream around every launch, summed per kernel class
         cl = lib()
         cl.ce_profile_class_name.restype = ctypes.c_char_p
+        # kernels are timed in isolation: both towers on ONE stream for this pass (in the timed region they
+        # overlap on two streams, which would stretch every per-kernel duration)
+        model.tower_streams = False
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
         cl.ce_profile_enable(1)
         n_prof = 2
         for _ in range(n_prof):
@@ -162,6 +171,7 @@ def main():
         buf = (ctypes.c_double * (ncls * 4))()
         cl.ce_profile_collect(buf, ncls)
         cl.ce_profile_enable(0)
+        model.tower_streams = not args.single_stream
         log("instrumented pass collected")
         rows = []
         for c in range(ncls):

@@ -65,14 +65,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dy: bf16 (DY_F32=false) or fp32.  dst row = rows ? rows[r] : r for x / dx (scatter form used
 // when only the CLS / EOT row of each sample went through the LayerNorm).
 template <int IT, bool DY_F32>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const int* __restrict__ rows,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ dx_in,
                                                      float* __restrict__ dx_out, long lddx, bf16_t* __restrict__ dxb,
                                                      long lddxb, float* __restrict__ dw, float* __restrict__ db,
                                                      float* __restrict__ dxsum, int M, int D) {
-    __shared__ float red[4 * 2048];
+    // 16 waves per workgroup, one row per wave at a time; at most 256 workgroups so that the per-column
+    // atomics (dgamma / dbeta / dx column sums) see little same-address contention
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [16][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 aw[IT], ab[IT], ax[IT], g[IT];
 #pragma unroll
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         g[i] = (c < D) ? *reinterpret_cast<const f32x4*>(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float invD = 1.0f / (float)D;
-    for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+    for (int r = blockIdx.x * 16 + wave; r < M; r += gridDim.x * 16) {
         const long dst = rows ? (long)rows[r] : (long)r;
         const float mu = mean[r], rs = rstd[r];
         f32x4 xh[IT], gy[IT];
@@ -136,12 +138,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = i * 256 + lane * 4;
-            if (c < D) *reinterpret_cast<f32x4*>(&red[wave * 2048 + c]) = pass == 0 ? aw[i] : (pass == 1 ? ab[i] : ax[i]);
+            if (c < D) *reinterpret_cast<f32x4*>(&red[wave * D + c]) = pass == 0 ? aw[i] : (pass == 1 ? ab[i] : ax[i]);
         }
         __syncthreads();
         float* dstp = pass == 0 ? dw : (pass == 1 ? db : dxsum);
-        for (int c = threadIdx.x; c < D; c += 256) {
-            float t = (red[c] + red[2048 + c]) + (red[4096 + c] + red[6144 + c]);
+        for (int c = threadIdx.x; c < D; c += 1024) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 16; ++wv) t += red[wv * D + c];
             atomicAdd(dstp + c, t);
         }
     }
@@ -183,17 +187,18 @@ extern "C" int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const flo
                                 int D, void* stream) {
     CE_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "ce_layernorm_bwd: need 0<D<=2048, D%%4==0 (D=%d M=%d)", D, M);
     CE_CHECK_ARG(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && lddxb % 4 == 0, "ce_layernorm_bwd: leading dimensions must be multiples of 4");
-    int blocks = ce_div_up(M, 4);
-    if (blocks > 1024) blocks = 1024;
-    dim3 grid(blocks), block(256);
+    int blocks = ce_div_up(M, 16);
+    if (blocks > 256) blocks = 256;
+    dim3 grid(blocks), block(1024);
+    const size_t lds = 16 * (size_t)D * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     CeProfScope prof(CE_PROF_LN_BWD, 16.0 * M * D, ((dy_f32 ? 4.0 : 2.0) + 4.0 + (dx_in ? 4.0 : 0.0) + 4.0 + (dxb ? 2.0 : 0.0)) * M * D, s);
 #define CALL(IT)                                                                                                    \
     if (dy_f32)                                                                                                     \
-        hipLaunchKernelGGL((ln_bwd_kernel<IT, true>), grid, block, 0, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \
+        hipLaunchKernelGGL((ln_bwd_kernel<IT, true>), grid, block, lds, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \
                            dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, dxsum, M, D);                                        \
     else                                                                                                            \
-        hipLaunchKernelGGL((ln_bwd_kernel<IT, false>), grid, block, 0, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \
+        hipLaunchKernelGGL((ln_bwd_kernel<IT, false>), grid, block, lds, s, dy, lddy, x, ldx, rows, mean, rstd, w, dx_in, \
                            dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, dxsum, M, D)
     LN_DISPATCH(D, CALL);
 #undef CALL

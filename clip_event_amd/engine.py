@@ -18,8 +18,7 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
     """Forward + criterion.  ``global_batch`` (W > 1): logits_per_image = s * I_local @ T_all^T,
     logits_per_text = s * T_local @ I_all^T with labels from ``distributed.global_labels``."""
     if D.world_size() > 1 and global_batch:
-        fi = model.encode_image(image)
-        ft = model.encode_text(text)
+        fi, ft = model.encode_both(image, text)
         fi_all, ft_all = D.gather_features(fi), D.gather_features(ft)
         overbatch = model.constrastive_overbatch
         lpi, _ = logits_from_features(fi, ft_all if overbatch else ft, model.logit_scale, overbatch, want="image")

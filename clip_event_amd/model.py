@@ -406,9 +406,36 @@ class CLIP(nn.Module):
         from .functional import EncodeTextFn
         return EncodeTextFn.apply(text, self._trigger, self)
 
+    def encode_both(self, image, text):
+        """Image and text towers of one step.  They are independent until the logits, so with
+        ``tower_streams`` (default) they run on two HIP streams: the ramp-up / tail of every kernel of one
+        tower (and the CUs a ragged tile grid leaves idle) is filled by the other tower's kernels.  The
+        autograd engine replays each tower's backward on its forward stream, so the backward overlaps too."""
+        self._ready()
+        if not getattr(self, "tower_streams", True):
+            return self.encode_image(image), self.encode_text(text)
+        if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != self._flat.device:
+            self._side_streams = (torch.cuda.Stream(device=self._flat.device), torch.cuda.Stream(device=self._flat.device))
+        s_img, s_txt = self._side_streams
+        cur = torch.cuda.current_stream()
+        s_img.wait_stream(cur)
+        s_txt.wait_stream(cur)
+        with torch.cuda.stream(s_img):
+            image_features = self.encode_image(image)
+        with torch.cuda.stream(s_txt):
+            text_features = self.encode_text(text)
+        cur.wait_stream(s_img)
+        cur.wait_stream(s_txt)
+        image_features.record_stream(cur)
+        text_features.record_stream(cur)
+        return image_features, text_features
+
     def forward(self, image, text, train_arg=None, bboxs=None, bbox_desc_vec=None, bbox_label_vec=None):
         """model_clip.py:419-528."""
         from .functional import logits_from_features
+        if train_arg is None:
+            image_features, text_features = self.encode_both(image, text)
+            return logits_from_features(image_features, text_features, self.logit_scale, self.constrastive_overbatch)
         image_features = self.encode_image(image, use_grid=train_arg is not None)
         if train_arg is not None:
             from .region import region_losses
