@@ -87,6 +87,39 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4
     }
 }
 
+// fused epilogue for 8 consecutive output columns n..n+7 of row m (bias already added)
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x4 v0, f32x4 v1) {
+    if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
+        u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + 4) = v1;
+    } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
+        const float* r = p.resid + (long)m * p.ldr + n;
+        v0 += *reinterpret_cast<const f32x4*>(r);
+        v1 += *reinterpret_cast<const f32x4*>(r + 4);
+        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + 4) = v1;
+    } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
+        u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+        u32x4 g = {pack_bf2(quick_gelu_f(v0[0]), quick_gelu_f(v0[1])), pack_bf2(quick_gelu_f(v0[2]), quick_gelu_f(v0[3])),
+                   pack_bf2(quick_gelu_f(v1[0]), quick_gelu_f(v1[1])), pack_bf2(quick_gelu_f(v1[2]), quick_gelu_f(v1[3]))};
+        *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + n) = g;
+    } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        u32x4 a = *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + n);
+        u32x4 o = {pack_bf2(v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0]))),
+                   pack_bf2(v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))),
+                   pack_bf2(v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2]))),
+                   pack_bf2(v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3])))};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,6 +236,27 @@ constexpr int N2_LDS_BYTES = 8 * 64 * 272;                 // 136 KiB: 2 stages 
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
+
+// LDS-DMA through inline asm: hipcc does not track asm memory operations, so it cannot serialise the DMA
+// against the fragment reads of the OTHER stage (it did, with the builtin, once the kernel grew an outer
+// loop: an s_waitcnt vmcnt(0) in front of every m-tile's first ds_read).  The kernel waits for the DMA
+// itself (vmcnt(0) ahead of the barrier that publishes a stage).  M0 (the LDS destination) is saved and
+// restored inside the statement; the leading s_nop covers SGPR-write -> VMEM-read wait states.
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void dma16_bounds(u32x4 rsrc, uint32_t lds_dst, uint32_t voff) {
+    uint32_t keep;
+    asm volatile(
+        "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_dst), "s"(rsrc)
+        : "memory");
+}
+
 
 template <int EPI, int TM>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
@@ -336,34 +390,117 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             if (m < p.M && gn < p.N) {
                 v0 += bias0;
                 v1 += bias1;
-                if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
-                    u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
-                } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
-                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + gn;
-                    *reinterpret_cast<f32x4*>(o) = v0;
-                    *reinterpret_cast<f32x4*>(o + 4) = v1;
-                } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
-                    const float* r = p.resid + (long)m * p.ldr + gn;
-                    v0 += *reinterpret_cast<const f32x4*>(r);
-                    v1 += *reinterpret_cast<const f32x4*>(r + 4);
-                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + gn;
-                    *reinterpret_cast<f32x4*>(o) = v0;
-                    *reinterpret_cast<f32x4*>(o + 4) = v1;
-                } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
-                    u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
-                    u32x4 g = {pack_bf2(quick_gelu_f(v0[0]), quick_gelu_f(v0[1])), pack_bf2(quick_gelu_f(v0[2]), quick_gelu_f(v0[3])),
-                               pack_bf2(quick_gelu_f(v1[0]), quick_gelu_f(v1[1])), pack_bf2(quick_gelu_f(v1[2]), quick_gelu_f(v1[3]))};
-                    *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + gn) = g;
-                } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
-                    u32x4 a = *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + gn);
-                    u32x4 o = {pack_bf2(v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0]))),
-                               pack_bf2(v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))),
-                               pack_bf2(v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2]))),
-                               pack_bf2(v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3])))};
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
-                }
+                nt_epilogue8<EPI>(p, m, gn, v0, v1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, 160x256x32 tile, 8 waves, SMALL footprint: 2 x 26 KiB LDS stages and <= 128 VGPRs, so two
+// (even three) workgroups share a CU and one workgroup's epilogue / prologue overlaps another's MFMA loop.
+// Used for the GEMMs that need several rounds of tiles (N = 3d, 4d); per-tile prologue+epilogue is ~40 % of
+// a K = 768 tile when a CU runs one workgroup at a time.  64-byte LDS rows, chunk swizzle
+// pos = chunk ^ 2*((row>>3)&1) (conflict-free for ds_read_b128, found by exhaustive search); operands arrive
+// by bounds-checked LDS-DMA (inline asm, counted by hand); the epilogue reuses the stage memory.
+// ------------------------------------------------------------------------------------------
+constexpr int N3_BM = 160, N3_BN = 256, N3_BK = 32, N3_TM = 5;
+constexpr int N3_A_BYTES = N3_BM * N3_BK * 2;               // 10 KiB
+constexpr int N3_STAGE_BYTES = (N3_BM + N3_BN) * N3_BK * 2;  // 26 KiB
+constexpr int N3_LDS_BYTES = 2 * N3_STAGE_BYTES;            // 52 KiB (>= 8 epilogue slices of 4352 B)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_nt32_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * N3_BM, n0 = tn * N3_BN;
+    const int rowsA = min(p.M - m0, N3_BM), rowsB = min(p.N - n0, N3_BN);
+    const u32x4 rA = make_rsrc_words(p.A + (long)m0 * p.lda, (uint32_t)((long)rowsA * p.lda * 2));
+    const u32x4 rB = make_rsrc_words(p.B + (long)n0 * p.ldb, (uint32_t)((long)rowsB * p.ldb * 2));
+
+    // DMA map: one instruction = 16 rows x 64 B; lane -> row l>>2, LDS position l&3, source chunk = pos ^ 2*((row>>3)&1)
+    const int s_row = lane >> 2;
+    const int s_chunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    const uint32_t vA0 = (uint32_t)((wave * 16 + s_row) * p.lda * 2 + s_chunk * 16);          // A instr = wave (and wave+8 if < 10)
+    const uint32_t vA1 = (uint32_t)(((wave + 8) * 16 + s_row) * p.lda * 2 + s_chunk * 16);
+    const uint32_t vB0 = (uint32_t)((wave * 16 + s_row) * p.ldb * 2 + s_chunk * 16);          // B instr = wave, wave+8
+    const uint32_t vB1 = (uint32_t)(((wave + 8) * 16 + s_row) * p.ldb * 2 + s_chunk * 16);
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem;
+    auto stage = [&](int st, int kt) {
+        const uint32_t base = lds0 + st * N3_STAGE_BYTES;
+        const uint32_t kb = (uint32_t)(kt * N3_BK * 2);
+        dma16_bounds(rA, base + wave * 1024, vA0 + kb);
+        if (wave < 2) dma16_bounds(rA, base + (wave + 8) * 1024, vA1 + kb);
+        dma16_bounds(rB, base + N3_A_BYTES + wave * 1024, vB0 + kb);
+        dma16_bounds(rB, base + N3_A_BYTES + (wave + 8) * 1024, vB1 + kb);
+    };
+
+    f32x4 acc[N3_TM][4];
+#pragma unroll
+    for (int i = 0; i < N3_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment map: row = base + (lane&15), chunk = lane>>4, position = chunk ^ 2*((lane>>3)&1)
+    const int f_pos = (lane >> 4) ^ (((lane >> 3) & 1) << 1);
+    const int fa_base = (wm * (N3_TM * 16) + (lane & 15)) * 64 + f_pos * 16;
+    const int fb_base = N3_A_BYTES + (wn * 64 + (lane & 15)) * 64 + f_pos * 16;
+
+    const int nk = p.K / N3_BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* st = smem + cur * N3_STAGE_BYTES;
+        bf16x8 wf[4], af[N3_TM];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 1024);
+#pragma unroll
+        for (int t = 0; t < N3_TM; ++t) af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + t * 1024);
+#pragma unroll
+        for (int t = 0; t < N3_TM; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[t][nt], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (this wave's DMA)
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS (stage memory is free after the last barrier): per wave 16-row x 64-col fp32 slices
+    constexpr int EROW = 272;
+    char* ebuf = smem + wave * (16 * EROW);
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;
+    const int gn = n0 + wn * 64 + e_c;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                  EPI == CE_EPI_BIAS_F32) {
+        if (gn < p.N) {
+            bias0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+            bias1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < N3_TM; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            *reinterpret_cast<f32x4*>(ebuf + (lane & 15) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) = acc[t][nt];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = m0 + wm * (N3_TM * 16) + t * 16 + it * 8 + e_r;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
+            if (m < p.M && gn < p.N) {
+                v0 += bias0;
+                v1 += bias1;
+                nt_epilogue8<EPI>(p, m, gn, v0, v1);
             }
         }
     }
@@ -523,26 +660,6 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p) {
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
-}
-
-// LDS-DMA through inline asm: hipcc does not track asm memory operations, so it cannot serialise the DMA
-// against the fragment reads of the OTHER stage (it did, with the builtin, once the kernel grew an outer
-// loop: an s_waitcnt vmcnt(0) in front of every m-tile's first ds_read).  The kernel waits for the DMA
-// itself (vmcnt(0) ahead of the barrier that publishes a stage).  M0 (the LDS destination) is saved and
-// restored inside the statement; the leading s_nop covers SGPR-write -> VMEM-read wait states.
-__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
-    const uint64_t a = (uint64_t)base;
-    u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-    return r;
-}
-__device__ __forceinline__ void dma16_bounds(u32x4 rsrc, uint32_t lds_dst, uint32_t voff) {
-    uint32_t keep;
-    asm volatile(
-        "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(lds_dst), "s"(rsrc)
-        : "memory");
 }
 
 // up to 4 weight-gradient problems that share the contraction length M (one residual block's four
@@ -721,6 +838,8 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt32_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
         attr_set = true;
     }
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
@@ -733,8 +852,12 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         // pick the tile height by wave quantisation: cost ~ (rounds over 256 CUs) x (rows per tile)
         const long t8 = (long)ce_div_up(a.M, 256) * a.tiles_n, t5 = (long)ce_div_up(a.M, 160) * a.tiles_n;
         const long c8 = ((t8 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 160;
-        const bool use5 = force_tm() == 5 || (force_tm() == 0 && c5 < c8);
-        if (use5) {
+        const bool use5 = force_tm() == 5 || (force_tm() == 0 && c5 * 11 < c8 * 10);
+        const bool use32 = force_tm() == 32 || (force_tm() == 0 && t5 > 320 && a.K % N3_BK == 0);
+        if (use32) {
+            a.tiles_m = ce_div_up(a.M, N3_BM);
+            hipLaunchKernelGGL(gemm_nt32_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N3_LDS_BYTES, stream, a);
+        } else if (use5) {
             a.tiles_m = ce_div_up(a.M, 160);
             hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
         } else {

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Epilogue cost of the NT GEMM at the MLP shapes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from clip_event_amd import ops, _lib as L
+from tools.bench_ops import timeit
+DEV = "cuda:0"
+for name, M, N, K in [("v.fc", 12800, 3072, 768), ("v.proj", 12800, 768, 3072), ("t.fc", 19712, 2048, 512), ("v.out", 12800, 768, 768)]:
+    a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    b = (torch.randn(N, K, device=DEV) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV)
+    resid = torch.randn(M, N, device=DEV)
+    aux = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    o16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); o16b = torch.empty_like(o16)
+    o32 = torch.empty(M, N, device=DEV)
+    for en, fn in [("BF16", lambda: ops.gemm_nt(a, b, L.EPI_BF16, out=o16)),
+                   ("BIAS_BF16", lambda: ops.gemm_nt(a, b, L.EPI_BIAS_BF16, bias=bias, out=o16)),
+                   ("F32", lambda: ops.gemm_nt(a, b, L.EPI_F32, out=o32)),
+                   ("RESID", lambda: ops.gemm_nt(a, b, L.EPI_BIAS_RESID_F32, bias=bias, resid=resid, out=o32)),
+                   ("GELU", lambda: ops.gemm_nt(a, b, L.EPI_BIAS_GELU, bias=bias, out=o16, out2=o16b)),
+                   ("GELUGRAD", lambda: ops.gemm_nt(a, b, L.EPI_GELUGRAD_BF16, aux=aux, out=o16))]:
+        t = timeit(fn)
+        print(f"{name:7s} {en:10s} {t*1e6:8.1f} us {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
