@@ -209,6 +209,19 @@ __global__ void eot_rows_kernel(const long* __restrict__ ids, int* __restrict__ 
     rows[r] = (int)(r * Ltok + arg);
 }
 
+// dst[dst_rows ? dst_rows[i] : i, :] = src[src_rows ? src_rows[i] : i, :]   (row_bytes multiple of 16)
+__global__ void copy_rows_kernel(const char* __restrict__ src, long src_stride, const int* __restrict__ src_rows,
+                                 char* __restrict__ dst, long dst_stride, const int* __restrict__ dst_rows, int n,
+                                 int chunks) {
+    const long total = (long)n * chunks;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / chunks), c = (int)(idx - (long)i * chunks);
+        const long sr = src_rows ? src_rows[i] : i, dr = dst_rows ? dst_rows[i] : i;
+        *reinterpret_cast<u32x4*>(dst + dr * dst_stride + c * 16L) =
+            *reinterpret_cast<const u32x4*>(src + sr * src_stride + c * 16L);
+    }
+}
+
 int grid_for(long threads, int block = 256, int cap = 8192) {
     long g = (threads + block - 1) / block;
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -303,6 +316,17 @@ extern "C" int ce_eot_rows(const int64_t* ids, int* rows, long n, int tokens, vo
     CE_CHECK_ARG(n > 0 && tokens > 0, "ce_eot_rows: bad shape");
     hipLaunchKernelGGL(eot_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const long*)ids, rows, n, tokens);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_copy_rows(const void* src, long src_stride_bytes, const int* src_rows, void* dst,
+                            long dst_stride_bytes, const int* dst_rows, int n, int row_bytes, void* stream) {
+    CE_CHECK_ARG(n > 0 && row_bytes > 0 && row_bytes % 16 == 0 && src_stride_bytes % 16 == 0 && dst_stride_bytes % 16 == 0,
+                 "ce_copy_rows: rows must be multiples of 16 bytes");
+    const int chunks = row_bytes / 16;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long)n * chunks)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, src_stride_bytes, src_rows, (char*)dst, dst_stride_bytes, dst_rows, n, chunks);
     CE_LAUNCH_CHECK();
     return 0;
 }

@@ -37,6 +37,9 @@ struct Layout {
     static constexpr int MAX_LAYERS = 64;
     BlockStash blk[MAX_LAYERS];
     bf16_t *dxb, *dxb2, *dh, *da, *dqkv, *d_o;
+    // compact [batch, .] buffers of the pruned last block
+    float *xs_in, *xs_mid, *dxs_mid, *means, *rstds;
+    bf16_t *os, *h2s, *as, *gs, *dxbs, *dxb2s, *das, *dhs, *dos;
     size_t bytes;
 };
 
@@ -65,6 +68,12 @@ void carve(const ce_tower_desc* d, int batch, void* ws, Layout& L) {
     L.da = c.take<bf16_t>(M * 4 * w);
     L.dqkv = c.take<bf16_t>(M * 3 * w);
     L.d_o = c.take<bf16_t>(M * w);
+    const size_t Bn = (size_t)batch;
+    L.xs_in = c.take<float>(Bn * w); L.xs_mid = c.take<float>(Bn * w); L.dxs_mid = c.take<float>(Bn * w);
+    L.means = c.take<float>(Bn); L.rstds = c.take<float>(Bn);
+    L.os = c.take<bf16_t>(Bn * w); L.h2s = c.take<bf16_t>(Bn * w); L.as = c.take<bf16_t>(Bn * 4 * w); L.gs = c.take<bf16_t>(Bn * 4 * w);
+    L.dxbs = c.take<bf16_t>(Bn * w); L.dxb2s = c.take<bf16_t>(Bn * w); L.das = c.take<bf16_t>(Bn * 4 * w);
+    L.dhs = c.take<bf16_t>(Bn * w); L.dos = c.take<bf16_t>(Bn * w);
     L.bytes = (c.off + 255) & ~size_t(255);
 }
 
@@ -93,7 +102,7 @@ extern "C" size_t ce_tower_workspace_bytes(const ce_tower_desc* d, int batch) {
 }
 
 extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* x_out,
-                                void* stream) {
+                                const int* sel_rows, void* stream) {
     TRY(check_desc(d, batch));
     CE_CHECK_ARG(x0 && workspace && x_out, "ce_tower_forward: null buffer");
     Layout L;
@@ -108,6 +117,21 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, const float* 
         TRY(ce_gemm_nt(s.h1, w, p.w_qkv, w, M, 3 * w, w, CE_EPI_BIAS_BF16, p.b_qkv, nullptr, 0, s.qkv, 3 * w, nullptr, 0,
                        nullptr, 0, stream));
         TRY(ce_attention_fwd(s.qkv, 3 * w, s.o, w, s.lse, batch, d->tokens, d->heads, d->causal, stream));
+        if (sel_rows && l + 1 == d->layers) {
+            // pruned last block: only the selected token of each sample feeds the head, so the out-projection
+            // and the MLP run on `batch` rows (75 % of this block's GEMM work is never needed)
+            const int Bn = batch;
+            TRY(ce_copy_rows(s.o, w * 2L, sel_rows, L.os, w * 2L, nullptr, Bn, w * 2, stream));
+            TRY(ce_copy_rows(x, w * 4L, sel_rows, L.xs_in, w * 4L, nullptr, Bn, w * 4, stream));
+            TRY(ce_gemm_nt(L.os, w, p.w_out, w, Bn, w, w, CE_EPI_BIAS_RESID_F32, p.b_out, L.xs_in, w, L.xs_mid, w, nullptr,
+                           0, nullptr, 0, stream));
+            TRY(ce_layernorm_fwd(L.xs_mid, w, nullptr, p.ln2_w, p.ln2_b, L.h2s, w, 0, L.means, L.rstds, Bn, w, 1e-5f, stream));
+            TRY(ce_gemm_nt(L.h2s, w, p.w_fc, w, Bn, 4 * w, w, CE_EPI_BIAS_GELU, p.b_fc, nullptr, 0, L.as, 4 * w, L.gs, 4 * w,
+                           nullptr, 0, stream));
+            TRY(ce_gemm_nt(L.gs, 4 * w, p.w_proj, 4 * w, Bn, w, 4 * w, CE_EPI_BIAS_RESID_F32, p.b_proj, L.xs_mid, w, x_out, w,
+                           nullptr, 0, nullptr, 0, stream));
+            break;
+        }
         TRY(ce_gemm_nt(s.o, w, p.w_out, w, M, w, w, CE_EPI_BIAS_RESID_F32, p.b_out, x, w, s.x_mid, w, nullptr, 0, nullptr,
                        0, stream));
         TRY(ce_layernorm_fwd(s.x_mid, w, nullptr, p.ln2_w, p.ln2_b, s.h2, w, 0, s.mean2, s.rstd2, M, w, 1e-5f, stream));
@@ -121,7 +145,7 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, const float* 
 }
 
 extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx,
-                                 void* stream) {
+                                 const int* sel_rows, const float* dx_sel, void* stream) {
     TRY(check_desc(d, batch));
     CE_CHECK_ARG(x0 && workspace && dx, "ce_tower_backward: null buffer");
     Layout L;
@@ -132,8 +156,55 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
     // block's four weight gradients run as ONE grouped launch after the last dgrad.
     bf16_t* dxb_a = L.dxb;
     bf16_t* dxb_b = L.dxb2;
-    TRY(ce_cast_bf16(dx, dxb_a, (long)M * w, stream));
-    for (int l = d->layers - 1; l >= 0; --l) {
+    int top = d->layers - 1;
+    if (sel_rows) {
+        // ---- pruned last block (see ce_tower_forward): compact rows through the MLP and the out-projection ----
+        CE_CHECK_ARG(dx_sel, "ce_tower_backward: pruned mode needs dx_sel");
+        const int l = top, Bn = batch;
+        const ce_block_params& p = d->blocks[l];
+        BlockStash& s = L.blk[l];
+        const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
+        TRY(ce_cast_bf16(dx_sel, L.dxbs, (long)Bn * w, stream));
+        TRY(ce_gemm_nt(L.dxbs, w, p.wt_proj, w, Bn, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.das, 4 * w, nullptr,
+                       0, L.as, 4 * w, stream));
+        TRY(ce_colsum_bf16(L.dxbs, w, p.g_b_proj, Bn, w, stream));
+        TRY(ce_gemm_nt(L.das, 4 * w, p.wt_fc, 4 * w, Bn, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dhs, w, nullptr, 0,
+                       nullptr, 0, stream));
+        TRY(ce_colsum_bf16(L.das, 4 * w, p.g_b_fc, Bn, 4 * w, stream));
+        TRY(ce_layernorm_bwd(L.dhs, w, 0, L.xs_mid, w, nullptr, L.means, L.rstds, p.ln2_w, dx_sel, L.dxs_mid, w, L.dxb2s, w,
+                             p.g_ln2_w, p.g_ln2_b, p.g_b_out, Bn, w, stream));
+        TRY(ce_gemm_nt(L.dxb2s, w, p.wt_out, w, Bn, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.dos, w, nullptr, 0, nullptr, 0,
+                       stream));
+        {
+            const void* P[3] = {L.dxbs, L.das, L.dxb2s};
+            const long ldp[3] = {w, 4L * w, w};
+            const void* Q[3] = {L.gs, L.h2s, L.os};
+            const long ldq[3] = {4L * w, w, w};
+            const int Nn[3] = {w, 4 * w, w};
+            const int Kk[3] = {4 * w, w, w};
+            float* out[3] = {p.g_w_proj, p.g_w_fc, p.g_w_out};
+            const long ldo[3] = {4L * w, w, w};
+            TRY(ce_gemm_tn_grouped(3, P, ldp, Q, ldq, Bn, Nn, Kk, out, ldo, 0, stream));
+        }
+        // attention sees dO only on the selected rows
+        if (hipMemsetAsync(L.d_o, 0, (size_t)M * w * 2, (hipStream_t)stream) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
+        TRY(ce_copy_rows(L.dos, w * 2L, nullptr, L.d_o, w * 2L, sel_rows, Bn, w * 2, stream));
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
+                             stream));
+        TRY(ce_gemm_nt(L.dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+                       nullptr, 0, stream));
+        TRY(ce_colsum_bf16(L.dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
+        TRY(ce_gemm_tn(L.dqkv, 3 * w, s.h1, w, M, 3 * w, w, p.g_w_qkv, w, 0, stream));
+        // residual path: dx = scatter(dx at x_mid of the selected rows), then + ln_1 backward
+        if (hipMemsetAsync(dx, 0, (size_t)M * w * 4, (hipStream_t)stream) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
+        TRY(ce_copy_rows(L.dxs_mid, w * 4L, nullptr, dx, w * 4L, sel_rows, Bn, w * 4, stream));
+        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, dxb_a, w, p.g_ln1_w,
+                             p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
+        top = l - 1;
+    } else {
+        TRY(ce_cast_bf16(dx, dxb_a, (long)M * w, stream));
+    }
+    for (int l = top; l >= 0; --l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;

@@ -68,17 +68,17 @@ class EncodeImageFn(torch.autograd.Function):
                                   ptr(x0), c_long(D), c_int(1), ptr(mean_pre), ptr(rstd_pre), c_int(M), c_int(D),
                                   c_float(1e-5), s), "ce_layernorm_fwd(ln_pre)")
         lease = _tower_workspace(model, model._vdesc, B, "vision")
-        xN = _empty((M, D), torch.float32, dev)
-        check(cl.ce_tower_forward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(xN), s),
-              "ce_tower_forward(vision)")
         if use_grid:
             rows, n = None, M
-        else:
+        else:                      # only the CLS row of each image is consumed (model_clip.py:256): pruned last block
             rows = (torch.arange(B, device=dev, dtype=torch.int32) * T)
             n = B
+        xN = _empty((n, D), torch.float32, dev)
+        check(cl.ce_tower_forward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(xN), ptr(rows), s),
+              "ce_tower_forward(vision)")
         hpost = _empty((n, D), torch.bfloat16, dev)
         mean_post, rstd_post = _empty((n,), torch.float32, dev), _empty((n,), torch.float32, dev)
-        check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), ptr(rows), ptr(P["visual.ln_post.weight"]),
+        check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), None, ptr(P["visual.ln_post.weight"]),
                                   ptr(P["visual.ln_post.bias"]), ptr(hpost), c_long(D), c_int(0), ptr(mean_post),
                                   ptr(rstd_post), c_int(n), c_int(D), c_float(1e-5), s), "ce_layernorm_fwd(ln_post)")
         feat = _empty((n, E), torch.float32, dev)
@@ -115,13 +115,19 @@ class EncodeImageFn(torch.autograd.Function):
                             c_long(0), s), "ce_gemm_nt(dproj)")
         check(cl.ce_gemm_tn(ptr(hpost), c_long(D), ptr(dfb), c_long(E), c_int(n), c_int(D), c_int(E),
                             ptr(G("visual.proj")), c_long(E), c_int(0), s), "ce_gemm_tn(visual.proj)")
-        dx = torch.zeros((M, D), dtype=torch.float32, device=dev) if rows is not None else _empty((M, D), torch.float32, dev)
-        check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), ptr(rows), ptr(mean_post),
-                                  ptr(rstd_post), ptr(P["visual.ln_post.weight"]), None, ptr(dx), c_long(D), None,
+        dxn = _empty((n, D), torch.float32, dev)          # gradient w.r.t. the tower output ([B,D] pruned / [M,D] grid)
+        check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), None, ptr(mean_post),
+                                  ptr(rstd_post), ptr(P["visual.ln_post.weight"]), None, ptr(dxn), c_long(D), None,
                                   c_long(0), ptr(G("visual.ln_post.weight")), ptr(G("visual.ln_post.bias")), None, c_int(n),
                                   c_int(D), s), "ce_layernorm_bwd(ln_post)")
-        check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), s),
-              "ce_tower_backward(vision)")
+        if rows is None:
+            dx = dxn
+            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), None, None, s),
+                  "ce_tower_backward(vision)")
+        else:
+            dx = _empty((M, D), torch.float32, dev)
+            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), ptr(rows),
+                                       ptr(dxn), s), "ce_tower_backward(vision)")
         lease.release()
         # ln_pre: x0 = LN(xpre)
         dxpre = _empty((M, D), torch.float32, dev)
@@ -167,14 +173,14 @@ class EncodeTextFn(torch.autograd.Function):
         check(cl.ce_token_embed(ptr(text), ptr(P["token_embedding.weight"]), ptr(P["positional_embedding"]), ptr(x0),
                                 c_long(M), c_int(T), c_int(D), c_int(model.vocab_size), s), "ce_token_embed")
         lease = _tower_workspace(model, model._tdesc, n, "text")
-        xN = _empty((M, D), torch.float32, dev)
-        check(cl.ce_tower_forward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(xN), s),
-              "ce_tower_forward(text)")
-        rows = _empty((n,), torch.int32, dev)
+        rows = _empty((n,), torch.int32, dev)              # EOT row of each caption (argmax token id, model_clip.py:415)
         check(cl.ce_eot_rows(ptr(text), ptr(rows), c_long(n), c_int(T), s), "ce_eot_rows")
+        xN = _empty((n, D), torch.float32, dev)            # pruned last block: only the EOT rows are produced
+        check(cl.ce_tower_forward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(xN), ptr(rows), s),
+              "ce_tower_forward(text)")
         hfin = _empty((n, D), torch.bfloat16, dev)
         mean_f, rstd_f = _empty((n,), torch.float32, dev), _empty((n,), torch.float32, dev)
-        check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), ptr(rows), ptr(P["ln_final.weight"]), ptr(P["ln_final.bias"]),
+        check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), None, ptr(P["ln_final.weight"]), ptr(P["ln_final.bias"]),
                                   ptr(hfin), c_long(D), c_int(0), ptr(mean_f), ptr(rstd_f), c_int(n), c_int(D),
                                   c_float(1e-5), s), "ce_layernorm_fwd(ln_final)")
         feat = _empty((n, E), torch.float32, dev)
@@ -207,13 +213,14 @@ class EncodeTextFn(torch.autograd.Function):
                             c_long(0), s), "ce_gemm_nt(dtext_projection)")
         check(cl.ce_gemm_tn(ptr(hfin), c_long(D), ptr(dfb), c_long(E), c_int(n), c_int(D), c_int(E),
                             ptr(G("text_projection")), c_long(E), c_int(0), s), "ce_gemm_tn(text_projection)")
-        dx = torch.zeros((M, D), dtype=torch.float32, device=dev)
-        check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), ptr(rows), ptr(mean_f), ptr(rstd_f),
-                                  ptr(P["ln_final.weight"]), None, ptr(dx), c_long(D), None, c_long(0),
+        dxn = _empty((n, D), torch.float32, dev)
+        check(cl.ce_layernorm_bwd(ptr(dh), c_long(D), c_int(0), ptr(xN), c_long(D), None, ptr(mean_f), ptr(rstd_f),
+                                  ptr(P["ln_final.weight"]), None, ptr(dxn), c_long(D), None, c_long(0),
                                   ptr(G("ln_final.weight")), ptr(G("ln_final.bias")), None, c_int(n), c_int(D), s),
               "ce_layernorm_bwd(ln_final)")
-        check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(dx), s),
-              "ce_tower_backward(text)")
+        dx = _empty((M, D), torch.float32, dev)
+        check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(dx), ptr(rows),
+                                   ptr(dxn), s), "ce_tower_backward(text)")
         lease.release()
         check(cl.ce_batch_reduce(ptr(dx), ptr(G("positional_embedding")), c_int(n), c_long(T * D), c_long(T * D),
                                  c_int(1), s), "ce_batch_reduce(text pos)")

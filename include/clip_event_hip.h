@@ -116,6 +116,9 @@ int ce_colsum_bf16(const void* x, long ld, float* out, int M, int N, void* strea
 /* fp32 master weight [R,C] -> bf16 copy [R,C] (nullable) and bf16 transposed copy [C,R] (nullable) */
 int ce_cast_transpose(const float* w, void* w16, long ld16, void* w16t, long ld16t, int R, int C, void* stream);
 int ce_cast_bf16(const float* x, void* y, long n, void* stream);
+/* gather / scatter whole rows: dst[dst_rows?dst_rows[i]:i] = src[src_rows?src_rows[i]:i], 16-byte granules */
+int ce_copy_rows(const void* src, long src_stride_bytes, const int* src_rows, void* dst, long dst_stride_bytes,
+                 const int* dst_rows, int n, int row_bytes, void* stream);
 /* rows[r] = r*tokens + argmax_t ids[r,t]  (EOT gather index, model_clip.py:415; first maximum) */
 int ce_eot_rows(const int64_t* ids, int* rows, long n, int tokens, void* stream);
 
@@ -170,12 +173,18 @@ typedef struct ce_tower_desc {
 /* bytes of activation stash + backward scratch for `batch` samples */
 size_t ce_tower_workspace_bytes(const ce_tower_desc* d, int batch);
 /* x_out[B*T, width] (f32) = blocks(x0[B*T, width] (f32)); stash kept in `workspace` for the backward;
- * x0 must stay valid until ce_tower_backward has run. */
+ * x0 must stay valid until ce_tower_backward has run.
+ * sel_rows (int32 [B], flat row index of the ONE token per sample whose output is consumed: CLS for the
+ * image tower, model_clip.py:256; EOT for the text tower, :415) selects the pruned mode: the last block's
+ * out-projection and MLP run on those B rows only (the other rows of the last block's output are never read
+ * by the reference either) and x_out is [B, width]. */
 int ce_tower_forward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* x_out,
-                     void* stream);
-/* dx (f32 [B*T, width]): in = gradient w.r.t. x_out, out = gradient w.r.t. x0 (in place);
- * parameter gradients are accumulated into the g_* buffers. */
-int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx, void* stream);
+                     const int* sel_rows, void* stream);
+/* dx (f32 [B*T, width]) = gradient w.r.t. x0.  Full mode (sel_rows NULL): dx holds the gradient w.r.t. x_out on
+ * entry (in place).  Pruned mode: dx_sel (f32 [B, width]) is the gradient w.r.t. the [B, width] output and dx is
+ * output only.  Parameter gradients are accumulated into the g_* buffers. */
+int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx,
+                      const int* sel_rows, const float* dx_sel, void* stream);
 
 /* ---- optimal-transport alignment + region pooling (ot.hip) ---- */
 /* dist[b] = trace(C_b T_b): cosine cost between txt[b] (M rows) and img[b] (N rows), IPOT plan
