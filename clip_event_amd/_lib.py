@@ -23,6 +23,12 @@ class HipExtensionMissing(RuntimeError):
     pass
 
 
+class TransposeJob(ctypes.Structure):
+    """``ce_transpose_job`` of include/clip_event_hip.h."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("tile_start", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 def lib() -> ctypes.CDLL:
     """Load the shared library once; fail loudly when it has not been built."""
     global _lib

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float* __restrict__ m, float* __restrict__ v, bf16_t* __restrict__ p16, long n,
                                                    const float* __restrict__ sumsq, float max_norm, float lr, float b1,
                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt) {
     float coef = 1.0f;
@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 pv[e] -= (lr / bc1) * (mv[e] / denom);
             }
             *reinterpret_cast<f32x4*>(p + i) = pv;
+            if (p16) {
+                u32x2 pk = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
+                *reinterpret_cast<u32x2*>(p16 + i) = pk;
+            }
             *reinterpret_cast<f32x4*>(m + i) = mv;
             *reinterpret_cast<f32x4*>(v + i) = vv;
         } else {
@@ -64,12 +68,47 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 p[k] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2_sqrt + eps));
                 m[k] = mk;
                 v[k] = vk;
+                if (p16) p16[k] = f2bf(p[k]);
             }
         }
     }
 }
 
+// dst[c][r] = src[r][c] for a table of bf16 matrices, one launch: the transposed operand copies of every
+// weight (input-gradient GEMMs read W^T) are rebuilt from the bf16 mirror the Adam kernel wrote.
+__global__ __launch_bounds__(256) void multi_transpose_kernel(const ce_transpose_job* __restrict__ jobs, int njobs) {
+    __shared__ bf16_t tile[64][66];
+    int j = 0;
+    const int b = blockIdx.x;
+    while (j + 1 < njobs && b >= jobs[j + 1].tile_start) ++j;      // block-uniform
+    const ce_transpose_job job = jobs[j];
+    const int t = b - job.tile_start;
+    const int tiles_c = (job.cols + 63) / 64;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(job.src);
+    bf16_t* dst = reinterpret_cast<bf16_t*>(job.dst);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;        // 64 x 4
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        tile[ty + 4 * k][tx] = (r < job.rows && c < job.cols) ? src[(long)r * job.cols + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < job.rows && c < job.cols) dst[(long)c * job.rows + r] = tile[tx][ty + 4 * k];
+    }
+}
+
 }  // namespace
+
+extern "C" int ce_multi_transpose_bf16(const ce_transpose_job* jobs_device, int njobs, int total_tiles, void* stream) {
+    CE_CHECK_ARG(jobs_device && njobs > 0 && total_tiles > 0, "ce_multi_transpose_bf16: empty");
+    hipLaunchKernelGGL(multi_transpose_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ce_sumsq(const float* g, long n, float* out, void* stream) {
     CE_CHECK_ARG(n > 0, "ce_sumsq: empty");
@@ -80,15 +119,15 @@ extern "C" int ce_sumsq(const float* g, long n, float* out, void* stream) {
     return 0;
 }
 
-extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float max_norm,
-                            float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* sumsq,
+                            float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                             void* stream) {
     CE_CHECK_ARG(n > 0 && step >= 1, "ce_adam_step: need n>0 and step>=1");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     long blocks = (n + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq,
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, sumsq,
                        max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
     CE_LAUNCH_CHECK();
     return 0;

@@ -319,22 +319,45 @@ class CLIP(nn.Module):
         dev = self._flat.device
         self._w16: Dict[str, torch.Tensor] = {}
         self._w16t: Dict[str, torch.Tensor] = {}
+        # bf16 mirror of the whole flat parameter buffer (same offsets): the straight [out,in] operand copies
+        # are views of it; the fused Adam kernel writes it together with the fp32 masters.
+        self._flat16 = torch.empty(self._flat.numel(), dtype=torch.bfloat16, device=dev)
+
+        def view16(n, shape=None):
+            p = self._pmap[n]
+            o = self._offsets[n]
+            return self._flat16[o: o + p.numel()].view(p.shape if shape is None else shape)
+
         gemm_names = [n for n in self._pmap if n.endswith(_GEMM_SUFFIXES)]
         for n in gemm_names:
             p = self._pmap[n]
-            self._w16[n] = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)
+            self._w16[n] = view16(n)
             self._w16t[n] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=dev)
         v = self.visual
         kp = 3 * v.patch_size * v.patch_size
         if kp % 8 != 0:
             raise NotImplementedError(f"patch size {v.patch_size}: 3*p*p must be a multiple of 8 for the bf16 patch GEMM")
         self._kp = kp
-        self._w16["visual.conv1.weight"] = torch.empty(self.vision_width, kp, dtype=torch.bfloat16, device=dev)
+        self._w16["visual.conv1.weight"] = view16("visual.conv1.weight", (self.vision_width, kp))
         for n in ("visual.proj", "text_projection"):
             p = self._pmap[n]
-            self._w16[n] = torch.empty(p.shape, dtype=torch.bfloat16, device=dev)                 # [width, E]
+            self._w16[n] = view16(n)                                                               # [width, E]
             self._w16t[n] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=dev)  # [E, width]
         self._cast_list = gemm_names + ["visual.conv1.weight", "visual.proj", "text_projection"]
+        # one-launch transposition table for every W^T copy
+        from ._lib import TransposeJob
+        names_t = list(self._w16t.keys())
+        jobs = (TransposeJob * len(names_t))()
+        tiles = 0
+        for i, n in enumerate(names_t):
+            src, dst = self._w16[n], self._w16t[n]
+            jobs[i].src, jobs[i].dst = src.data_ptr(), dst.data_ptr()
+            jobs[i].rows, jobs[i].cols, jobs[i].tile_start = src.shape[0], src.shape[1], tiles
+            tiles += ((src.shape[0] + 63) // 64) * ((src.shape[1] + 63) // 64)
+        raw = bytes(jobs)
+        self._tjobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._tjobs_n, self._tjobs_tiles = len(names_t), tiles
+        self._mirror_fresh = False        # True when the Adam kernel has just written _flat16
 
         def desc(prefix: str, tr: Transformer, tokens: int, causal: bool):
             arr = (_BlockParams * tr.layers)()
@@ -375,18 +398,19 @@ class CLIP(nn.Module):
             return
         s = stream()
         cl = lib()
-        for n in self._cast_list:
-            p = self._pmap[n]
-            if n == "visual.conv1.weight":
-                check(cl.ce_cast_bf16(ptr(p), ptr(self._w16[n]), c_long(p.numel()), s), "ce_cast_bf16")
-            else:
-                w16, w16t = self._w16[n], self._w16t[n]
-                check(cl.ce_cast_transpose(ptr(p), ptr(w16), c_long(w16.stride(0)), ptr(w16t), c_long(w16t.stride(0)),
-                                           c_int(p.shape[0]), c_int(p.shape[1]), s), "ce_cast_transpose")
+        if not self._mirror_fresh:
+            # masters changed outside the fused optimiser: rebuild the whole bf16 mirror (one launch)
+            check(cl.ce_cast_bf16(ptr(self._flat), ptr(self._flat16), c_long(self._flat.numel()), s), "ce_cast_bf16")
+        check(cl.ce_multi_transpose_bf16(ptr(self._tjobs), c_int(self._tjobs_n), c_int(self._tjobs_tiles), s),
+              "ce_multi_transpose_bf16")
+        self._mirror_fresh = False
         self._versions = vers
 
-    def mark_operands_stale(self):
+    def mark_operands_stale(self, mirror_fresh: bool = False):
+        """``mirror_fresh``: the caller (fused Adam) has already written the bf16 mirror of the new masters,
+        only the transposed copies need rebuilding."""
         self._versions = None
+        self._mirror_fresh = mirror_fresh
 
     def _ready(self):
         if not self._flat_ok():

@@ -51,7 +51,7 @@ class FusedAdam:
             self.sumsq.zero_()
             check(lib().ce_sumsq(ptr(m._flat_grad), c_long(n), ptr(self.sumsq), s), "ce_sumsq")
             sumsq = self.sumsq
-        check(lib().ce_adam_step(ptr(m._flat), ptr(m._flat_grad), ptr(self.m), ptr(self.v), c_long(n), ptr(sumsq),
+        check(lib().ce_adam_step(ptr(m._flat), ptr(m._flat_grad), ptr(self.m), ptr(self.v), ptr(m._flat16), c_long(n), ptr(sumsq),
                                  c_float(self.max_norm or 0.0), c_float(lr), c_float(self.betas[0]), c_float(self.betas[1]),
                                  c_float(self.eps), c_float(self.weight_decay), c_int(self.step_count), s), "ce_adam_step")
-        m.mark_operands_stale()
+        m.mark_operands_stale(mirror_fresh=True)

@@ -147,8 +147,17 @@ int ce_elem_loss_bwd(const float* x, const float* y, long n, int mode, const flo
 
 /* ---- optimiser (optim.hip): clip_grad_norm_(.,max_norm) + Adam(L2 weight decay), engine.py:89-90 ---- */
 int ce_sumsq(const float* g, long n, float* out, void* stream);
-int ce_adam_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float max_norm, float lr,
-                 float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* p_bf16 (nullable): bf16 mirror of the updated parameters, same flat layout (the GEMM operand copies) */
+int ce_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* sumsq, float max_norm,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* dst[c][r] = src[r][c] (bf16, dense) for a device table of matrices in one launch; tile_start = running
+ * count of 64x64 tiles (jobs sorted by it) */
+typedef struct ce_transpose_job {
+    const void* src;
+    void* dst;
+    int rows, cols, tile_start, pad_;
+} ce_transpose_job;
+int ce_multi_transpose_bf16(const ce_transpose_job* jobs_device, int njobs, int total_tiles, void* stream);
 
 /* ---- transformer tower runner (tower.cpp): the 12x ResidualAttentionBlock loop of
  * Transformer.forward (model_clip.py:171-211) and its backward, all launches issued from C++ ---- */
