@@ -89,7 +89,7 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4
 
 // fused epilogue for 8 consecutive output columns n..n+7 of row m (bias already added)
 template <int EPI>
-__device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x4 v0, f32x4 v1) {
+__device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4& cs0, f32x4& cs1) {
     if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
         u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
@@ -112,10 +112,13 @@ __device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x
         *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + n) = g;
     } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
         u32x4 a = *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + n);
-        u32x4 o = {pack_bf2(v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0]))),
-                   pack_bf2(v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))),
-                   pack_bf2(v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2]))),
-                   pack_bf2(v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3])))};
+        f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
+                    v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
+        f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
+                    v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
+        cs0 += r0;      // column sums of the result = bias gradient of the Linear whose pre-activation this is
+        cs1 += r1;
+        u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
     }
 }
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     const int e_r = lane >> 3, e_c = (lane & 7) * 8;          // row-phase map: row e_r (+8/iter), 8 columns
     const int gn = n0 + wn * 64 + e_c;
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
                   EPI == CE_EPI_BIAS_F32) {
         if (gn < p.N) {
@@ -390,7 +394,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
             if (m < p.M && gn < p.N) {
                 v0 += bias0;
                 v1 += bias1;
-                nt_epilogue8<EPI>(p, m, gn, v0, v1);
+                nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+            }
+        }
+    }
+    if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        if (p.out2) {   // fused bias gradient: reduce the 8 lanes that own the same 8 columns, one atomic per column per wave
+            float* colsum = reinterpret_cast<float*>(p.out2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    cs0[e] += __shfl_xor(cs0[e], o, 64);
+                    cs1[e] += __shfl_xor(cs1[e], o, 64);
+                }
+            }
+            if (lane < 8 && gn < p.N) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(colsum + gn + e, cs0[e]);
+                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
+                }
             }
         }
     }
@@ -480,6 +504,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt32_kernel(NTArgs p) {
     const int e_r = lane >> 3, e_c = (lane & 7) * 8;
     const int gn = n0 + wn * 64 + e_c;
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
                   EPI == CE_EPI_BIAS_F32) {
         if (gn < p.N) {
@@ -500,7 +525,27 @@ __global__ __launch_bounds__(512, 4) void gemm_nt32_kernel(NTArgs p) {
             if (m < p.M && gn < p.N) {
                 v0 += bias0;
                 v1 += bias1;
-                nt_epilogue8<EPI>(p, m, gn, v0, v1);
+                nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+            }
+        }
+    }
+    if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        if (p.out2) {   // fused bias gradient: reduce the 8 lanes that own the same 8 columns, one atomic per column per wave
+            float* colsum = reinterpret_cast<float*>(p.out2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    cs0[e] += __shfl_xor(cs0[e], o, 64);
+                    cs1[e] += __shfl_xor(cs1[e], o, 64);
+                }
+            }
+            if (lane < 8 && gn < p.N) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(colsum + gn + e, cs0[e]);
+                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
+                }
             }
         }
     }
@@ -866,6 +911,10 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         }
     } else {
         hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
+        if (EPI == CE_EPI_GELUGRAD_BF16 && a.out2) {   // the 128^2 kernel has no fused column sums
+            CE_LAUNCH_CHECK();
+            return ce_colsum_bf16(a.out, a.ldo, reinterpret_cast<float*>(a.out2), a.M, a.N, stream);
+        }
     }
     CE_LAUNCH_CHECK();
     return 0;

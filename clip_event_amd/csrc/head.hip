@@ -47,53 +47,56 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     }
 }
 
-// C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + beta * C[m,n]; 64x64 tile, 4x4 per thread
+// C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + beta * C[m,n]; TxT tile, (T/16)x(T/16) per thread.
+// T = 64 for big problems, T = 32 when a 64-tile grid would leave most of the chip idle (B = 256 logits).
+template <int T>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long sam, long sak,
                                                     const float* __restrict__ B, long sbk, long sbn,
                                                     float* __restrict__ C, long ldc, int M, int N, int K,
                                                     const float* __restrict__ alpha_ptr, float alpha, int alpha_exp,
                                                     float beta) {
-    __shared__ float sA[16][65];
-    __shared__ float sB[16][65];
+    constexpr int R = T / 16;
+    __shared__ float sA[16][T + 1];
+    __shared__ float sB[16][T + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    float acc[4][4] = {};
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    float acc[R][R] = {};
     for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+        for (int idx = threadIdx.x; idx < T * 16; idx += 256) {
             // map so that the fastest-varying thread index follows the unit-stride axis of each operand
             int kk, mm;
-            if (sak == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+            if (sak == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx % T; kk = idx / T; }
             const int m = m0 + mm, k = k0 + kk;
             sA[kk][mm] = (m < M && k < K) ? A[(long)m * sam + (long)k * sak] : 0.f;
             int kb, nn;
-            if (sbk == 1) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
+            if (sbk == 1) { kb = idx & 15; nn = idx >> 4; } else { nn = idx % T; kb = idx / T; }
             const int n = n0 + nn, k2 = k0 + kb;
             sB[kb][nn] = (n < N && k2 < K) ? B[(long)k2 * sbk + (long)n * sbn] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
+            float a[R], b[R];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < R; ++i) {
                 a[i] = sA[kk][ty + 16 * i];
                 b[i] = sB[kk][tx + 16 * i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+                for (int j = 0; j < R; ++j) acc[i][j] += a[i] * b[j];
         }
         __syncthreads();
     }
     float al = alpha;
     if (alpha_ptr) al *= alpha_exp ? __expf(*alpha_ptr) : *alpha_ptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R; ++i) {
         const int m = m0 + ty + 16 * i;
         if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < R; ++j) {
             const int n = n0 + tx + 16 * j;
             if (n >= N) continue;
             float v = al * acc[i][j];
@@ -239,8 +242,15 @@ extern "C" int ce_sgemm(const float* A, long sam, long sak, const float* B, long
                         int M, int N, int K, const float* alpha_ptr, float alpha, int alpha_exp, float beta,
                         void* stream) {
     CE_CHECK_ARG(M > 0 && N > 0 && K > 0, "ce_sgemm: empty");
-    hipLaunchKernelGGL(sgemm_kernel, dim3(ce_div_up(N, 64), ce_div_up(M, 64)), dim3(256), 0, (hipStream_t)stream, A, sam,
-                       sak, B, sbk, sbn, C, ldc, M, N, K, alpha_ptr, alpha, alpha_exp, beta);
+    if ((long)ce_div_up(N, 64) * ce_div_up(M, 64) >= 256)
+        hipLaunchKernelGGL(sgemm_kernel<64>, dim3(ce_div_up(N, 64), ce_div_up(M, 64)), dim3(256), 0, (hipStream_t)stream, A,
+                           sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha_ptr, alpha, alpha_exp, beta);
+    else if ((long)ce_div_up(N, 32) * ce_div_up(M, 32) >= 256)
+        hipLaunchKernelGGL(sgemm_kernel<32>, dim3(ce_div_up(N, 32), ce_div_up(M, 32)), dim3(256), 0, (hipStream_t)stream, A,
+                           sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha_ptr, alpha, alpha_exp, beta);
+    else
+        hipLaunchKernelGGL(sgemm_kernel<16>, dim3(ce_div_up(N, 16), ce_div_up(M, 16)), dim3(256), 0, (hipStream_t)stream, A,
+                           sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha_ptr, alpha, alpha_exp, beta);
     CE_LAUNCH_CHECK();
     return 0;
 }

@@ -209,13 +209,12 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         BlockStash& s = L.blk[l];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         // ---- mlp.c_proj : x_out = x_mid + g Wp^T + bp ----
-        TRY(ce_gemm_nt(dxb_a, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.da, 4 * w, nullptr,
-                       0, s.a, 4 * w, stream));                                   // da = (dx Wp) * gelu'(a)
+        TRY(ce_gemm_nt(dxb_a, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.da, 4 * w, p.g_b_fc,
+                       4 * w, s.a, 4 * w, stream));                               // da = (dx Wp) * gelu'(a); g_b_fc += colsum(da)
         if (l == d->layers - 1) TRY(ce_colsum_bf16(dxb_a, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
         // ---- mlp.c_fc : a = h2 Wf^T + bf ----
         TRY(ce_gemm_nt(L.da, 4 * w, p.wt_fc, 4 * w, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh2 = da Wf
-        TRY(ce_colsum_bf16(L.da, 4 * w, p.g_b_fc, M, 4 * w, stream));
         // ---- ln_2 (+ residual); also the column sums of dx = attn.out_proj bias gradient ----
         TRY(ce_layernorm_bwd(L.dh, w, 0, s.x_mid, w, nullptr, s.mean2, s.rstd2, p.ln2_w, dx, dx, w, dxb_b, w, p.g_ln2_w,
                              p.g_ln2_b, p.g_b_out, M, w, stream));

@@ -51,7 +51,8 @@ enum {
     CE_EPI_BIAS_F32 = 3,      /* out(f32)  = acc + bias[n]                                  */
     CE_EPI_BIAS_RESID_F32 = 4,/* out(f32)  = resid(f32) + acc + bias[n]     (x + proj(..))  */
     CE_EPI_BIAS_GELU = 5,     /* out(bf16) = a = acc + bias; out2(bf16) = a*sigmoid(1.702a) */
-    CE_EPI_GELUGRAD_BF16 = 6  /* out(bf16) = acc * dQuickGELU(aux(bf16))                    */
+    CE_EPI_GELUGRAD_BF16 = 6  /* out(bf16) = acc * dQuickGELU(aux(bf16)); out2 (nullable) is reused as a
+                               * float[N] that receives += the column sums of out (bias gradient)      */
 };
 
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue.

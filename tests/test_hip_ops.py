@@ -185,3 +185,25 @@ def test_gemm_tn_fused_bias_grad(M, Nn, Kk):
     torch.cuda.synchronize()
     assert _report(f"tn+bias {M}x{Nn}x{Kk} dW", out.cpu(), p.float().t() @ q.float())[1] < 2e-5
     assert _report("tn+bias db", bg.cpu(), p.float().sum(0))[1] < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 256), (6400, 3072, 128), (400, 512, 256)])
+def test_gemm_nt_gelugrad_fused_colsum(M, N, K):
+    """GELUGRAD epilogue with out2 = float[N]: += column sums of the output (the c_fc bias gradient)."""
+    from ctypes import c_int, c_long
+    from clip_event_amd._lib import check, lib, ptr, stream, EPI_GELUGRAD_BF16
+    rng = np.random.default_rng(M + N + K)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    aux = _randn(rng, M, N).to(torch.bfloat16)
+    A, B, AUX = a.to(DEV), b.to(DEV), aux.to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    cs = torch.zeros(N, device=DEV)
+    check(lib().ce_gemm_nt(ptr(A), c_long(K), ptr(B), c_long(K), c_int(M), c_int(N), c_int(K), c_int(EPI_GELUGRAD_BF16), None,
+                           None, c_long(0), ptr(out), c_long(N), ptr(cs), c_long(N), ptr(AUX), c_long(N), stream()), "gemm")
+    torch.cuda.synchronize()
+    x = aux.float()
+    s = torch.sigmoid(1.702 * x)
+    ref = (a.float() @ b.float().t()) * (s * (1 + 1.702 * x * (1 - s)))
+    assert _report("gelugrad out", out.float().cpu(), ref)[1] < 3e-3
+    assert _report("gelugrad colsum", cs.cpu(), ref.sum(0))[1] < 2e-3
