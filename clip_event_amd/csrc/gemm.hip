@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
 // 240-248 workgroups for the 256 CUs where 256-row tiles give 150.
 constexpr int N2_BN = 256, N2_BK = 64;
 constexpr int N2_BTILE_BYTES = N2_BN * N2_BK * 2;           // 32 KiB
+constexpr int N2H_LDS_BYTES = 2 * (160 + 128) * 64 * 2;     // 72 KiB: 160x128 tile, two stages (>= 4 epilogue slices)
 constexpr int N2_LDS_BYTES = 8 * 64 * 272;                 // 136 KiB: 2 stages (<=128 KiB) or 8 epilogue slices of 17 KiB
 
 typedef __attribute__((address_space(1))) const void gptr_t;
@@ -261,18 +262,25 @@ __device__ __forceinline__ void dma16_bounds(u32x4 rsrc, uint32_t lds_dst, uint3
 }
 
 
-template <int EPI, int TM>
-__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
+// WN = waves along N (64 columns each): 4 -> 8 waves, 256-column tile, one workgroup per CU;
+//                                      2 -> 4 waves, 128-column tile, 72 KiB LDS: TWO workgroups per CU, so one's
+//                                      prologue / epilogue overlaps the other's K loop, and N = width GEMMs get
+//                                      480-496 tiles for the 512 slots.
+template <int EPI, int TM, int WN>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
+    constexpr int NW = 2 * WN;                                  // waves per workgroup
+    constexpr int N2_BN = 64 * WN;
+    constexpr int N2_BTILE_BYTES = N2_BN * N2_BK * 2;
     constexpr int N2_BM = 32 * TM;
     constexpr int N2_TILE_BYTES = N2_BM * N2_BK * 2;            // A tile
     constexpr int N2_STAGE_BYTES = N2_TILE_BYTES + N2_BTILE_BYTES;
     constexpr int A_INSTR = N2_BM / 8;                          // 1-KiB DMA instructions per A tile
-    constexpr int A_PER_WAVE = (A_INSTR + 7) / 8;
+    constexpr int A_PER_WAVE = (A_INSTR + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
@@ -285,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
     const bf16_t* gA[A_PER_WAVE];
     const bf16_t* gB[4];
 #pragma unroll
-    for (int i = 0; i < A_PER_WAVE; ++i) {    // A instruction index = wave + 8*i (wave-uniform bound check below)
-        const int row = (wave + 8 * i) * 8 + s_r;
+    for (int i = 0; i < A_PER_WAVE; ++i) {    // A instruction index = wave + NW*i (wave-uniform bound check below)
+        const int row = (wave + NW * i) * 8 + s_r;
         const int ra = min(m0 + row, p.M - 1);                                  // clamp: rows past the edge are never stored
         gA[i] = p.A + (long)ra * p.lda + s_chunk * 8;
     }
@@ -302,8 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs p) {
         const int koff = kt * N2_BK;
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; ++i)
-            if (wave + 8 * i < A_INSTR)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(gA[i] + koff), (lptr_t*)(sa + (wave + 8 * i) * 1024), 16, 0, 0);
+            if (wave + NW * i < A_INSTR)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(gA[i] + koff), (lptr_t*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(gB[i] + koff), (lptr_t*)(sb + i * 1024), 16, 0, 0);
@@ -879,10 +887,12 @@ int launch_nt(NTArgs a, hipStream_t stream) {
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 8>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 8, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N2H_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt32_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
         attr_set = true;
@@ -899,15 +909,20 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         const long c8 = ((t8 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 160;
         const bool use5 = force_tm() == 5 || (force_tm() == 0 && c5 * 11 < c8 * 10);
         const bool use32 = force_tm() == 32 || (force_tm() == 0 && t5 > 320 && a.K % N3_BK == 0);
+        const bool use4w = force_tm() == 4;   // 160x128, two workgroups per CU: measured equal to the 8-wave 160x256 tile, kept as an option
         if (use32) {
             a.tiles_m = ce_div_up(a.M, N3_BM);
             hipLaunchKernelGGL(gemm_nt32_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N3_LDS_BYTES, stream, a);
+        } else if (use4w) {
+            a.tiles_m = ce_div_up(a.M, 160);
+            a.tiles_n = ce_div_up(a.N, 128);
+            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), N2H_LDS_BYTES, stream, a);
         } else if (use5) {
             a.tiles_m = ce_div_up(a.M, 160);
-            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
         } else {
             a.tiles_m = ce_div_up(a.M, 256);
-            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 8>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 8, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
         }
     } else {
         hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);

@@ -7,11 +7,48 @@
 //   x_in f32 (previous block's output), h1 bf16, qkv bf16 [M,3d], o bf16, lse f32,
 //   x_mid f32, h2 bf16, a bf16 [M,4d] (pre-GELU), g bf16 [M,4d], LayerNorm mean/rstd.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
 
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
 namespace {
+
+// Weight gradients are off the critical path of the backward chain (nothing downstream of a block reads them),
+// so each tower CAN issue them on a SIDE stream (off by default, CE_WGRAD_STREAM=1): they overlap the memory-bound kernels of the dgrad chain
+// (LayerNorm / attention backward, where the MFMA units idle) instead of serialising with them.
+// One context per caller stream, created lazily: a non-blocking side stream and two events per block.
+struct SideCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t ready[64];
+    hipEvent_t done[64];
+    bool ok = false;
+};
+std::mutex g_side_mu;
+std::map<hipStream_t, SideCtx*> g_side;
+int g_wgrad_stream = -1;
+
+SideCtx* side_ctx(hipStream_t main) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (g_wgrad_stream < 0) {
+        const char* e = getenv("CE_WGRAD_STREAM");
+        g_wgrad_stream = e ? atoi(e) : 0;   // measured: with the two towers already on two streams the extra
+                                            // concurrency costs 3 % (cache / CU contention); kept as an option
+    }
+    if (!g_wgrad_stream) return nullptr;
+    auto it = g_side.find(main);
+    if (it != g_side.end()) return it->second->ok ? it->second : nullptr;
+    SideCtx* c = new SideCtx();
+    c->ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 64 && c->ok; ++i)
+        c->ok = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) == hipSuccess;
+    g_side[main] = c;
+    return c->ok ? c : nullptr;
+}
 
 struct Carver {
     char* base;
@@ -36,7 +73,9 @@ struct BlockStash {
 struct Layout {
     static constexpr int MAX_LAYERS = 64;
     BlockStash blk[MAX_LAYERS];
-    bf16_t *dxb, *dxb2, *dh, *da, *dqkv, *d_o;
+    bf16_t *dxb[2], *dxb2[2], *da[2], *dqkv[2];   // two sets (block parity): the side-stream wgrad of block l reads its
+                                                  // set while block l-1 already fills the other one
+    bf16_t *dh, *d_o;
     // compact [batch, .] buffers of the pruned last block
     float *xs_in, *xs_mid, *dxs_mid, *means, *rstds;
     bf16_t *os, *h2s, *as, *gs, *dxbs, *dxb2s, *das, *dhs, *dos;
@@ -62,11 +101,13 @@ void carve(const ce_tower_desc* d, int batch, void* ws, Layout& L) {
         s.rstd2 = c.take<float>(M);
         s.lse = c.take<float>((size_t)batch * d->heads * d->tokens);
     }
-    L.dxb = c.take<bf16_t>(M * w);
-    L.dxb2 = c.take<bf16_t>(M * w);
+    for (int q = 0; q < 2; ++q) {
+        L.dxb[q] = c.take<bf16_t>(M * w);
+        L.dxb2[q] = c.take<bf16_t>(M * w);
+        L.da[q] = c.take<bf16_t>(M * 4 * w);
+        L.dqkv[q] = c.take<bf16_t>(M * 3 * w);
+    }
     L.dh = c.take<bf16_t>(M * w);
-    L.da = c.take<bf16_t>(M * 4 * w);
-    L.dqkv = c.take<bf16_t>(M * 3 * w);
     L.d_o = c.take<bf16_t>(M * w);
     const size_t Bn = (size_t)batch;
     L.xs_in = c.take<float>(Bn * w); L.xs_mid = c.take<float>(Bn * w); L.dxs_mid = c.take<float>(Bn * w);
@@ -151,16 +192,28 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
     Layout L;
     carve(d, batch, workspace, L);
     const int M = batch * d->tokens, w = d->width;
-    // dxb_a: bf16 gradient at the block output (operand of mlp.c_proj's dgrad/wgrad);
-    // dxb_b: bf16 gradient at x_mid (operand of attn.out_proj's dgrad/wgrad).  Both stay alive until the
-    // block's four weight gradients run as ONE grouped launch after the last dgrad.
-    bf16_t* dxb_a = L.dxb;
-    bf16_t* dxb_b = L.dxb2;
-    int top = d->layers - 1;
+    // Per block l (buffer set q = l & 1): dxb_a = bf16 gradient at the block output (operand of mlp.c_proj's
+    // dgrad/wgrad, written by block l+1's ln_1 backward), dxb_b = bf16 gradient at x_mid (attn.out_proj), da,
+    // dqkv.  They stay alive until the block's four weight gradients have run as ONE grouped launch on the side
+    // stream; block l-2 (same set) may only overwrite them after that launch has finished.
+    hipStream_t ms = (hipStream_t)stream;
+    SideCtx* sc = side_ctx(ms);
+    void* wstream = sc ? (void*)sc->side : stream;
+    const int last = d->layers - 1;
+    auto mark_ready = [&](int l) {       // everything wgrad(l) reads has been enqueued on the main stream
+        if (sc) { hipEventRecord(sc->ready[l], ms); hipStreamWaitEvent(sc->side, sc->ready[l], 0); }
+    };
+    auto mark_done = [&](int l) {
+        if (sc) hipEventRecord(sc->done[l], sc->side);
+    };
+    auto wait_done = [&](int l) {        // main stream: do not overwrite set (l&1) before wgrad(l) has read it
+        if (sc && l >= 0 && l <= last) hipStreamWaitEvent(ms, sc->done[l], 0);
+    };
+    int top = last;
     if (sel_rows) {
         // ---- pruned last block (see ce_tower_forward): compact rows through the MLP and the out-projection ----
         CE_CHECK_ARG(dx_sel, "ce_tower_backward: pruned mode needs dx_sel");
-        const int l = top, Bn = batch;
+        const int l = top, Bn = batch, q = l & 1;
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
@@ -175,6 +228,12 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
                              p.g_ln2_w, p.g_ln2_b, p.g_b_out, Bn, w, stream));
         TRY(ce_gemm_nt(L.dxb2s, w, p.wt_out, w, Bn, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.dos, w, nullptr, 0, nullptr, 0,
                        stream));
+        // attention sees dO only on the selected rows
+        if (hipMemsetAsync(L.d_o, 0, (size_t)M * w * 2, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
+        TRY(ce_copy_rows(L.dos, w * 2L, nullptr, L.d_o, w * 2L, sel_rows, Bn, w * 2, stream));
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv[q], 3 * w, batch, d->tokens, d->heads, d->causal,
+                             stream));
+        mark_ready(l);
         {
             const void* P[3] = {L.dxbs, L.das, L.dxb2s};
             const long ldp[3] = {w, 4L * w, w};
@@ -184,36 +243,34 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
             const int Kk[3] = {4 * w, w, w};
             float* out[3] = {p.g_w_proj, p.g_w_fc, p.g_w_out};
             const long ldo[3] = {4L * w, w, w};
-            TRY(ce_gemm_tn_grouped(3, P, ldp, Q, ldq, Bn, Nn, Kk, out, ldo, 0, stream));
+            TRY(ce_gemm_tn_grouped(3, P, ldp, Q, ldq, Bn, Nn, Kk, out, ldo, 0, wstream));
         }
-        // attention sees dO only on the selected rows
-        if (hipMemsetAsync(L.d_o, 0, (size_t)M * w * 2, (hipStream_t)stream) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
-        TRY(ce_copy_rows(L.dos, w * 2L, nullptr, L.d_o, w * 2L, sel_rows, Bn, w * 2, stream));
-        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
-                             stream));
-        TRY(ce_gemm_nt(L.dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+        TRY(ce_gemm_tn(L.dqkv[q], 3 * w, s.h1, w, M, 3 * w, w, p.g_w_qkv, w, 0, wstream));
+        mark_done(l);
+        TRY(ce_gemm_nt(L.dqkv[q], 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));
-        TRY(ce_colsum_bf16(L.dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
-        TRY(ce_gemm_tn(L.dqkv, 3 * w, s.h1, w, M, 3 * w, w, p.g_w_qkv, w, 0, stream));
+        TRY(ce_colsum_bf16(L.dqkv[q], 3 * w, p.g_b_qkv, M, 3 * w, stream));
         // residual path: dx = scatter(dx at x_mid of the selected rows), then + ln_1 backward
-        if (hipMemsetAsync(dx, 0, (size_t)M * w * 4, (hipStream_t)stream) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
+        if (hipMemsetAsync(dx, 0, (size_t)M * w * 4, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
         TRY(ce_copy_rows(L.dxs_mid, w * 4L, nullptr, dx, w * 4L, sel_rows, Bn, w * 4, stream));
-        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, dxb_a, w, p.g_ln1_w,
+        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[q ^ 1], w, p.g_ln1_w,
                              p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
         top = l - 1;
     } else {
-        TRY(ce_cast_bf16(dx, dxb_a, (long)M * w, stream));
+        TRY(ce_cast_bf16(dx, L.dxb[top & 1], (long)M * w, stream));
     }
     for (int l = top; l >= 0; --l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
+        const int q = l & 1;
+        bf16_t *dxb_a = L.dxb[q], *dxb_b = L.dxb2[q], *da = L.da[q], *dqkv = L.dqkv[q];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         // ---- mlp.c_proj : x_out = x_mid + g Wp^T + bp ----
-        TRY(ce_gemm_nt(dxb_a, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.da, 4 * w, p.g_b_fc,
+        TRY(ce_gemm_nt(dxb_a, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, da, 4 * w, p.g_b_fc,
                        4 * w, s.a, 4 * w, stream));                               // da = (dx Wp) * gelu'(a); g_b_fc += colsum(da)
-        if (l == d->layers - 1) TRY(ce_colsum_bf16(dxb_a, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
+        if (l == last) TRY(ce_colsum_bf16(dxb_a, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
         // ---- mlp.c_fc : a = h2 Wf^T + bf ----
-        TRY(ce_gemm_nt(L.da, 4 * w, p.wt_fc, 4 * w, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+        TRY(ce_gemm_nt(da, 4 * w, p.wt_fc, 4 * w, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh2 = da Wf
         // ---- ln_2 (+ residual); also the column sums of dx = attn.out_proj bias gradient ----
         TRY(ce_layernorm_bwd(L.dh, w, 0, s.x_mid, w, nullptr, s.mean2, s.rstd2, p.ln2_w, dx, dx, w, dxb_b, w, p.g_ln2_w,
@@ -222,15 +279,12 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         TRY(ce_gemm_nt(dxb_b, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
                        stream));                                                  // d_o = dx Wo
         // ---- attention core ----
-        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
                              stream));
-        // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
-        TRY(ce_gemm_nt(L.dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
-                       nullptr, 0, stream));                                      // dh1 = dqkv Wqkv
-        TRY(ce_colsum_bf16(L.dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
-        // ---- the four weight gradients of this block, one launch ----
+        // ---- the four weight gradients of this block, one launch, on the side stream ----
+        mark_ready(l);
         {
-            const void* P[4] = {dxb_a, L.da, dxb_b, L.dqkv};
+            const void* P[4] = {dxb_a, da, dxb_b, dqkv};
             const long ldp[4] = {w, 4L * w, w, 3L * w};
             const void* Q[4] = {s.g, s.h2, s.o, s.h1};
             const long ldq[4] = {4L * w, w, w, w};
@@ -238,11 +292,25 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
             const int Kk[4] = {4 * w, w, w, w};
             float* out[4] = {p.g_w_proj, p.g_w_fc, p.g_w_out, p.g_w_qkv};
             const long ldo[4] = {4L * w, w, w, w};
-            TRY(ce_gemm_tn_grouped(4, P, ldp, Q, ldq, M, Nn, Kk, out, ldo, 0, stream));
+            TRY(ce_gemm_tn_grouped(4, P, ldp, Q, ldq, M, Nn, Kk, out, ldo, 0, wstream));
         }
-        // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient ----
-        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, dxb_a, w, p.g_ln1_w,
+        mark_done(l);
+        // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
+        TRY(ce_gemm_nt(dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+                       nullptr, 0, stream));                                      // dh1 = dqkv Wqkv
+        TRY(ce_colsum_bf16(dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
+        // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient.  It writes the
+        // other buffer set's dxb, which wgrad(l+1) may still be reading ----
+        wait_done(l + 1);
+        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[q ^ 1], w, p.g_ln1_w,
                              p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
     }
+    wait_done(0);
+    wait_done(1);
     return 0;
+}
+
+extern "C" void ce_tower_wgrad_stream(int on) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    g_wgrad_stream = on ? 1 : 0;
 }

@@ -214,6 +214,9 @@ int ce_bbox_pool_fwd(const float* grid, long sb, long s0, long s1, const int* bo
                      void* stream);
 int ce_bbox_pool_bwd(const float* dout, const int* boxes, float* dgrid, int g, int nbox, int E, void* stream);
 
+/* weight gradients of the tower backward on a side stream (default off; CE_WGRAD_STREAM=1 or this call turn it on) */
+void ce_tower_wgrad_stream(int on);
+
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);
 int ce_probe_tr16(const void* image, int n_elems, const int* byte_off, void* out, void* stream);
