@@ -141,7 +141,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ o, long ldo,
                                                        const bf16_t* __restrict__ dout, long lddo,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                       long lddq, int L, int H, int D, int causal, float scale) {
+                                                       long lddq, float* __restrict__ bias_grad, int L, int H, int D,
+                                                       int causal, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = T * 16;
     constexpr int PROW = Lp * 2 + 32;            // stride of the P^T / dS^T images: = 32 (mod 64) bytes
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     char* sDO = sV + Lp * ROW;
     char* sP = sDO + Lp * ROW;
     char* sDS = sP + Lp * PROW;
+    float* csum = reinterpret_cast<float*>(sDS + Lp * PROW);   // [3][64] column sums of dq | dk | dv (in_proj bias gradient)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     const bf16_t* ob = o + (long)b * L * ldo + h * HD;
     bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
 
+    for (int i = tid; i < 192; i += blockDim.x) csum[i] = 0.f;   // the workgroup may have fewer than 192 threads
     stage_head(sQ, base, ld, L, Lp, tid, blockDim.x);
     stage_head(sK, base + D, ld, L, Lp, tid, blockDim.x);
     stage_head(sV, base + 2 * D, ld, L, Lp, tid, blockDim.x);
@@ -238,6 +241,16 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 *reinterpret_cast<u32x2*>(qrow + ct * 16) = pk;
             }
         }
+        if (bias_grad) {   // sum over the strip's 16 queries (lanes of a 16-lane group); padded queries are exact zeros
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[ct][r];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (li == 0) atomicAdd(&csum[ct * 16 + 4 * g + r], v);
+                }
+        }
     }
     __syncthreads();
     // ---------------- phase 2: per 16-key tile ----------------
@@ -276,6 +289,24 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 *reinterpret_cast<u32x2*>(vrow + ct * 16) = pv;
             }
         }
+        if (bias_grad) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float vk = ak[ct][r], vv = av[ct][r];
+                    vk += __shfl_xor(vk, 1, 64); vk += __shfl_xor(vk, 2, 64); vk += __shfl_xor(vk, 4, 64); vk += __shfl_xor(vk, 8, 64);
+                    vv += __shfl_xor(vv, 1, 64); vv += __shfl_xor(vv, 2, 64); vv += __shfl_xor(vv, 4, 64); vv += __shfl_xor(vv, 8, 64);
+                    if (li == 0) {
+                        atomicAdd(&csum[64 + ct * 16 + 4 * g + r], vk);
+                        atomicAdd(&csum[128 + ct * 16 + 4 * g + r], vv);
+                    }
+                }
+        }
+    }
+    if (bias_grad) {
+        __syncthreads();
+        for (int i = tid; i < 192; i += blockDim.x) atomicAdd(bias_grad + (i >> 6) * D + h * HD + (i & 63), csum[i]);
     }
 }
 
@@ -315,8 +346,8 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
 }
 
 extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
-                                const float* lse, void* dqkv, long lddq, int B, int L, int H, int causal,
-                                void* stream) {
+                                const float* lse, void* dqkv, long lddq, float* bias_grad, int B, int L, int H,
+                                int causal, void* stream) {
     CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_bwd: empty problem");
     CE_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0, "ce_attention_bwd: bad leading dimension");
     const int D = H * HD;
@@ -324,7 +355,7 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
     const int Lp = T * 16;
     int nw = T;
     if (nw > 8) nw = 8;
-    const size_t lds = 4 * (size_t)Lp * ROW + 2 * (size_t)Lp * (Lp * 2 + 32);
+    const size_t lds = 4 * (size_t)Lp * ROW + 2 * (size_t)Lp * (Lp * 2 + 32) + 192 * sizeof(float);
     const float scale = 0.125f;
     hipStream_t s = (hipStream_t)stream;
     CeProfScope prof(CE_PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (8.0 * D), s);
@@ -337,8 +368,8 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
             attr = true;                                                                                           \
         }                                                                                                          \
         hipLaunchKernelGGL(attn_bwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld,        \
-                           (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, L, H, D, causal, \
-                           scale);                                                                                 \
+                           (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, \
+                           causal, scale);                                                                                 \
     } while (0)
     ATTN_DISPATCH(T, CALL);
 #undef CALL

@@ -231,8 +231,8 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         // attention sees dO only on the selected rows
         if (hipMemsetAsync(L.d_o, 0, (size_t)M * w * 2, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
         TRY(ce_copy_rows(L.dos, w * 2L, nullptr, L.d_o, w * 2L, sel_rows, Bn, w * 2, stream));
-        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv[q], 3 * w, batch, d->tokens, d->heads, d->causal,
-                             stream));
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv[q], 3 * w, p.g_b_qkv, batch, d->tokens, d->heads,
+                             d->causal, stream));
         mark_ready(l);
         {
             const void* P[3] = {L.dxbs, L.das, L.dxb2s};
@@ -249,7 +249,6 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         mark_done(l);
         TRY(ce_gemm_nt(L.dqkv[q], 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));
-        TRY(ce_colsum_bf16(L.dqkv[q], 3 * w, p.g_b_qkv, M, 3 * w, stream));
         // residual path: dx = scatter(dx at x_mid of the selected rows), then + ln_1 backward
         if (hipMemsetAsync(dx, 0, (size_t)M * w * 4, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
         TRY(ce_copy_rows(L.dxs_mid, w * 4L, nullptr, dx, w * 4L, sel_rows, Bn, w * 4, stream));
@@ -279,8 +278,8 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         TRY(ce_gemm_nt(dxb_b, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
                        stream));                                                  // d_o = dx Wo
         // ---- attention core ----
-        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, batch, d->tokens, d->heads, d->causal,
-                             stream));
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, p.g_b_qkv, batch, d->tokens, d->heads,
+                             d->causal, stream));
         // ---- the four weight gradients of this block, one launch, on the side stream ----
         mark_ready(l);
         {
@@ -298,7 +297,6 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
         TRY(ce_gemm_nt(dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh1 = dqkv Wqkv
-        TRY(ce_colsum_bf16(dqkv, 3 * w, p.g_b_qkv, M, 3 * w, stream));
         // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient.  It writes the
         // other buffer set's dxb, which wgrad(l+1) may still be reading ----
         wait_done(l + 1);

@@ -82,10 +82,10 @@ def attention_fwd(qkv: torch.Tensor, B: int, L: int, H: int, causal: bool):
     return o, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B: int, L: int, H: int, causal: bool):
+def attention_bwd(qkv, o, dout, lse, B: int, L: int, H: int, causal: bool, bias_grad=None):
     dqkv = torch.empty_like(qkv)
     check(lib().ce_attention_bwd(ptr(qkv), c_long(qkv.stride(0)), ptr(o), c_long(o.stride(0)), ptr(dout),
-                                 c_long(dout.stride(0)), ptr(lse), ptr(dqkv), c_long(dqkv.stride(0)), c_int(B), c_int(L),
+                                 c_long(dout.stride(0)), ptr(lse), ptr(dqkv), c_long(dqkv.stride(0)), ptr(bias_grad), c_int(B), c_int(L),
                                  c_int(H), c_int(1 if causal else 0), stream()), "ce_attention_bwd")
     return dqkv
 

@@ -93,8 +93,10 @@ int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const float* x, long
  * model_clip.py:188 (mask from model_clip.py:377-384). */
 int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, int B, int L, int H, int causal,
                      void* stream);
+/* bias_grad (f32 [3*H*64], nullable) += column sums of dqkv (the in_proj bias gradient) */
 int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
-                     const float* lse, void* dqkv, long lddq, int B, int L, int H, int causal, void* stream);
+                     const float* lse, void* dqkv, long lddq, float* bias_grad, int B, int L, int H, int causal,
+                     void* stream);
 
 /* ---- input side, bookkeeping (embed.hip) ---- */
 /* image f32 [B,3,R,R] -> patch rows bf16 [B*(R/p)^2, k_padded], columns ordered (c, py, px) like the

@@ -163,9 +163,11 @@ def test_attention_fwd_bwd(B, L, H, causal):
     assert _report("attn lse", lse.cpu().view(B, H, L), lse_ref.detach())[0] < 1e-3
     dout = _randn(rng, B * L, D).to(torch.bfloat16)
     o_ref.backward(dout.float())
-    dqkv = ops.attention_bwd(qkv.to(DEV), o, dout.to(DEV), lse, B, L, H, causal)
+    bg = torch.zeros(3 * D, device=DEV)
+    dqkv = ops.attention_bwd(qkv.to(DEV), o, dout.to(DEV), lse, B, L, H, causal, bias_grad=bg)
     torch.cuda.synchronize()
     g = qkv_r.grad
+    assert _report(f"attn in_proj bias grad L={L}", bg.cpu(), g.sum(0))[1] < 2e-2
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert _report(f"attn {name} L={L}", dqkv[:, sl].float().cpu(), g[:, sl])[1] < 2e-2
 
