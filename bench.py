@@ -101,10 +101,16 @@ def main():
     W = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CE_ALL_RANKS_ON_GPU0"):      # rehearsal of the N>1 path on a one-GPU box
+        local_rank = 0
     if W > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" == RCCL on ROCm
+        backend = os.environ.get("CE_DIST_BACKEND", "nccl")          # "nccl" == RCCL on ROCm; gloo only to rehearse
+        if backend == "nccl":                                        # several ranks on a one-GPU box
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -154,7 +160,7 @@ def main():
     pairs_per_s = B * W * args.steps / dt
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:     # every rank runs the instrumented steps (they contain collectives); rank 0 reports
         # instrumented pass: HIP events on the launch stream around every launch, summed per kernel class
         cl = lib()
         cl.ce_profile_class_name.restype = ctypes.c_char_p
@@ -177,7 +183,7 @@ def main():
         model.tower_streams = not args.single_stream
         log("instrumented pass collected")
         rows = []
-        for c in range(ncls):
+        for c in range(ncls if rank == 0 else 0):
             cnt, ms, fl, by = buf[c * 4:(c + 1) * 4]
             if cnt > 0:
                 rows.append({"kernel": cl.ce_profile_class_name(c).decode(), "launches_per_step": cnt / n_prof,
@@ -185,6 +191,7 @@ def main():
                              "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                              "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
         rows.sort(key=lambda r: -r["ms_per_step"])
+    if rank == 0 and not args.no_roofline and rows:
         top = rows[0]
         mfma = top["kernel"].startswith("gemm") or top["kernel"].startswith("attn")
         ach = top["tflops"] if mfma else top["gbps"]

@@ -41,7 +41,10 @@ class _AllGatherFn(torch.autograd.Function):
         W = dist.get_world_size()
         x = x.contiguous()
         out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x)
+        if dist.get_backend() == "gloo":          # rehearsal backend: list form
+            dist.all_gather(list(out.chunk(W, dim=0)), x)
+        else:
+            dist.all_gather_into_tensor(out, x)
         ctx.n = x.shape[0]
         return out
 
