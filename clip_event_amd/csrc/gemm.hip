@@ -429,6 +429,160 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// NT kernel, 160x256x64 tile, 8 waves, THREE-stage LDS ring (156 KiB), prefetch distance 2, hand-counted
+// LDS-DMA waits.  For the single-round GEMMs (N = width: one tile per CU, nothing else on the CU to hide
+// latency) the two-stage loop is DMA-latency bound: the tile issued at the top of an iteration must have landed
+// by its end.  Here every DMA gets two iterations to land and the wait before the barrier leaves the newest
+// stage in flight (vmcnt(7) / vmcnt(6): waves 0-3 issue 7 DMA instructions per stage, waves 4-7 issue 6).
+// ------------------------------------------------------------------------------------------
+constexpr int N4_BM = 160, N4_BN = 256, N4_BK = 64, N4_TM = 5;
+constexpr int N4_A_BYTES = N4_BM * N4_BK * 2;                // 20 KiB
+constexpr int N4_STAGE_BYTES = (N4_BM + N4_BN) * N4_BK * 2;   // 52 KiB
+constexpr int N4_LDS_BYTES = 3 * N4_STAGE_BYTES;             // 156 KiB (>= 8 epilogue slices of 17 KiB)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt160_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * N4_BM, n0 = tn * N4_BN;
+    const int rowsA = min(p.M - m0, N4_BM), rowsB = min(p.N - n0, N4_BN);
+    const u32x4 rA = make_rsrc_words(p.A + (long)m0 * p.lda, (uint32_t)((long)rowsA * p.lda * 2));
+    const u32x4 rB = make_rsrc_words(p.B + (long)n0 * p.ldb, (uint32_t)((long)rowsB * p.ldb * 2));
+
+    // DMA map: one instruction = 8 rows x 128 B; lane -> row l>>3, LDS position l&7, source chunk = pos ^ (row&7)
+    const int s_row = lane >> 3;
+    const int s_chunk = (lane & 7) ^ s_row;
+    uint32_t vA[3], vB[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vA[i] = (uint32_t)(((wave + 8 * i) * 8 + s_row) * p.lda * 2 + s_chunk * 16);   // A instr = wave + 8 i (< 20)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vB[i] = (uint32_t)(((wave * 4 + i) * 8 + s_row) * p.ldb * 2 + s_chunk * 16);   // B instr = 4 wave + i
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem;
+    auto stage = [&](int st, int kt) {
+        const uint32_t base = lds0 + st * N4_STAGE_BYTES;
+        const uint32_t kb = (uint32_t)(kt * N4_BK * 2);
+        dma16_bounds(rA, base + wave * 1024, vA[0] + kb);
+        dma16_bounds(rA, base + (wave + 8) * 1024, vA[1] + kb);
+        if (wave < 4) dma16_bounds(rA, base + (wave + 16) * 1024, vA[2] + kb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16_bounds(rB, base + N4_A_BYTES + (wave * 4 + i) * 1024, vB[i] + kb);
+    };
+    auto wait_prev = [&](bool newest_in_flight) {      // all but this wave's newest stage have landed
+        if (newest_in_flight) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    f32x4 acc[N4_TM][4];
+#pragma unroll
+    for (int i = 0; i < N4_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
+    const int fa_base = (wm * (N4_TM * 16) + f_row) * 128;
+    const int fb_base = N4_A_BYTES + (wn * 64 + f_row) * 128;
+
+    const int nk = p.K / N4_BK;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    wait_prev(nk > 1);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt2 = cur == 0 ? 2 : cur - 1;           // (cur + 2) % 3
+        if (kt + 2 < nk) stage(nxt2, kt + 2);
+        const char* st = smem + cur * N4_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + f_kc) ^ f_sw) << 4;
+            bf16x8 wf[4], af[N4_TM];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < N4_TM; ++t) af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + t * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < N4_TM; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[t][nt], 0, 0, 0);
+        }
+        wait_prev(kt + 2 < nk);                            // stage kt+1 landed; kt+2 may still be in flight
+        __syncthreads();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+    // ---- epilogue through LDS (ring memory is free after the last barrier): per wave 64-row x 64-col fp32 slices
+    constexpr int EROW = 272;
+    char* ebuf = smem + wave * (64 * EROW);
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;
+    const int gn = n0 + wn * 64 + e_c;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                  EPI == CE_EPI_BIAS_F32) {
+        if (gn < p.N) {
+            bias0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+            bias1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+        }
+    }
+#pragma unroll
+    for (int mh = 0; mh * 4 < N4_TM; ++mh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (mh * 4 + t < N4_TM) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    *reinterpret_cast<f32x4*>(ebuf + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) =
+                        acc[mh * 4 + t][nt];
+            }
+        const int gm0 = m0 + wm * (N4_TM * 16) + mh * 64 + e_r;
+        const int its = (N4_TM - mh * 4 >= 4) ? 8 : (N4_TM - mh * 4) * 2;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (it >= its) break;
+            const int m = gm0 + it * 8;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
+            if (m < p.M && gn < p.N) {
+                v0 += bias0;
+                v1 += bias1;
+                nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+            }
+        }
+    }
+    if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        if (p.out2) {
+            float* colsum = reinterpret_cast<float*>(p.out2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    cs0[e] += __shfl_xor(cs0[e], o, 64);
+                    cs1[e] += __shfl_xor(cs1[e], o, 64);
+                }
+            }
+            if (lane < 8 && gn < p.N) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(colsum + gn + e, cs0[e]);
+                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // NT kernel, 160x256x32 tile, 8 waves, SMALL footprint: 2 x 26 KiB LDS stages and <= 128 VGPRs, so two
 // (even three) workgroups share a CU and one workgroup's epilogue / prologue overlaps another's MFMA loop.
 // Used for the GEMMs that need several rounds of tiles (N = 3d, 4d); per-tile prologue+epilogue is ~40 % of
@@ -895,6 +1049,8 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2H_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt32_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         attr_set = true;
     }
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
@@ -907,7 +1063,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         // pick the tile height by wave quantisation: cost ~ (rounds over 256 CUs) x (rows per tile)
         const long t8 = (long)ce_div_up(a.M, 256) * a.tiles_n, t5 = (long)ce_div_up(a.M, 160) * a.tiles_n;
         const long c8 = ((t8 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 160;
-        const bool use5 = force_tm() == 5 || (force_tm() == 0 && c5 * 11 < c8 * 10);
+        const bool use5 = force_tm() == 5 || force_tm() == 160 || (force_tm() == 0 && c5 * 11 < c8 * 10);
         const bool use32 = force_tm() == 32 || (force_tm() == 0 && t5 > 320 && a.K % N3_BK == 0);
         const bool use4w = force_tm() == 4;   // 160x128, two workgroups per CU: measured equal to the 8-wave 160x256 tile, kept as an option
         if (use32) {
@@ -917,6 +1073,10 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             a.tiles_m = ce_div_up(a.M, 160);
             a.tiles_n = ce_div_up(a.N, 128);
             hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), N2H_LDS_BYTES, stream, a);
+        } else if (use5 && force_tm() == 160) {      // three-stage ring: measured 6 % slower than the two-stage loop (the
+                                                     // K loop is LDS-bandwidth bound, not DMA-latency bound); kept as an option
+            a.tiles_m = ce_div_up(a.M, 160);
+            hipLaunchKernelGGL(gemm_nt160_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N4_LDS_BYTES, stream, a);
         } else if (use5) {
             a.tiles_m = ce_div_up(a.M, 160);
             hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
