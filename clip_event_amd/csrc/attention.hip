@@ -143,14 +143,14 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                        long lddq, float* __restrict__ bias_grad, int L, int H, int D,
                                                        int causal, float scale) {
+    // LDS: two [Lp][64] operand images (K,V in phase 1; re-filled with Q,dO for phase 2) + the P / dS images
+    // [query i][key j] + 192 floats.  74 KiB at L=77 (two workgroups per CU), 41 KiB at L=50 (three).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = T * 16;
-    constexpr int PROW = Lp * 2 + 32;            // stride of the P^T / dS^T images: = 32 (mod 64) bytes
-    char* sQ = smem;
-    char* sK = sQ + Lp * ROW;
-    char* sV = sK + Lp * ROW;
-    char* sDO = sV + Lp * ROW;
-    char* sP = sDO + Lp * ROW;
+    constexpr int PROW = Lp * 2 + 32;            // row stride of the P / dS images: = 32 (mod 64) bytes
+    char* sA = smem;                             // K, then Q
+    char* sB = sA + Lp * ROW;                    // V, then dO
+    char* sP = sB + Lp * ROW;
     char* sDS = sP + Lp * PROW;
     float* csum = reinterpret_cast<float*>(sDS + Lp * PROW);   // [3][64] column sums of dq | dk | dv (in_proj bias gradient)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,10 +162,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
 
     for (int i = tid; i < 192; i += blockDim.x) csum[i] = 0.f;   // the workgroup may have fewer than 192 threads
-    stage_head(sQ, base, ld, L, Lp, tid, blockDim.x);
-    stage_head(sK, base + D, ld, L, Lp, tid, blockDim.x);
-    stage_head(sV, base + 2 * D, ld, L, Lp, tid, blockDim.x);
-    stage_head(sDO, dob, lddo, L, Lp, tid, blockDim.x);
+    stage_head(sA, base + D, ld, L, Lp, tid, blockDim.x);        // K
+    stage_head(sB, base + 2 * D, ld, L, Lp, tid, blockDim.x);    // V
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
@@ -189,11 +187,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
             dl += __shfl_xor(dl, 32, 64);
         }
         const float lsei = lse[((long)b * H + h) * L + iq];
-        bf16x8 qf[2], df[2];
+        bf16x8 qf[2], df[2];       // B operands: rows of Q and dO straight from global (only this wave needs them)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(sQ + iq * ROW + (ks * 4 + g) * 16);
-            df[ks] = *reinterpret_cast<const bf16x8*>(sDO + iq * ROW + (ks * 4 + g) * 16);
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+            df[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)iq * lddo + ks * 32 + g * 8);
         }
         f32x4 p[T], ds[T];
 #pragma unroll
@@ -202,8 +200,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
             ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sA + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(sB + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
                 p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], p[t], 0, 0, 0);     // S^T
                 ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[ks], ds[t], 0, 0, 0);   // dP^T
             }
@@ -214,10 +212,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 const float pv = ok ? __expf(p[t][r] * scale - lsei) : 0.f;
                 p[t][r] = pv;
                 ds[t][r] = pv * (ds[t][r] - dl) * scale;
-                // P^T / dS^T images [j][i] for phase 2
-                *reinterpret_cast<bf16_t*>(sP + j * PROW + i * 2) = f2bf(pv);
-                *reinterpret_cast<bf16_t*>(sDS + j * PROW + i * 2) = f2bf(ds[t][r]);
             }
+            // P / dS images [i][j] for phase 2: this lane owns 4 consecutive keys of query i -> one 8-byte store each
+            u32x2 pk = {pack_bf2(p[t][0], p[t][1]), pack_bf2(p[t][2], p[t][3])};
+            u32x2 dk = {pack_bf2(ds[t][0], ds[t][1]), pack_bf2(ds[t][2], ds[t][3])};
+            *reinterpret_cast<u32x2*>(sP + i * PROW + (t * 16 + g * 4) * 2) = pk;
+            *reinterpret_cast<u32x2*>(sDS + i * PROW + (t * 16 + g * 4) * 2) = dk;
         }
         // dQ^T = K^T dS^T (dS^T straight from the accumulators, K^T by transposed reads)
         f32x4 acc[4];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int sidx = 0; sidx < T / 2; ++sidx) {
             bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
-            const char* krow = sK + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+            const char* krow = sA + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf16x8 kf = tr_pair(krow + ct * 32, krow + ct * 32 + 16 * ROW);
@@ -252,6 +252,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 }
         }
     }
+    __syncthreads();                                             // K, V no longer needed; P / dS images complete
+    stage_head(sA, base, ld, L, Lp, tid, blockDim.x);            // Q
+    stage_head(sB, dob, lddo, L, Lp, tid, blockDim.x);           // dO
     __syncthreads();
     // ---------------- phase 2: per 16-key tile ----------------
     const int nkt = (L + 15) >> 4;
@@ -265,15 +268,19 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         }
 #pragma unroll
         for (int sidx = 0; sidx < T / 2; ++sidx) {
-            // B operands: P[i][j] / dS[i][j] as 8 consecutive i of row j of the transposed images
-            bf16x8 pf = *reinterpret_cast<const bf16x8*>(sP + j * PROW + (32 * sidx + 8 * g) * 2);
-            bf16x8 sf = *reinterpret_cast<const bf16x8*>(sDS + j * PROW + (32 * sidx + 8 * g) * 2);
-            // A operands: dO^T / Q^T rows c, contraction i = 32s + 8g + jj (natural order)
-            const int roff = (32 * sidx + 8 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+            // contraction i = 32s + 8g + jj (natural order) for both operands
+            const int irow = 32 * sidx + 8 * g + (li >> 2);
+            // B operands: P[i][j], dS[i][j] = 8 consecutive queries of key column j -> transposed reads of the [i][j] images
+            const char* pcol = sP + irow * PROW + (jt * 16 + 4 * (li & 3)) * 2;
+            const char* scol = sDS + irow * PROW + (jt * 16 + 4 * (li & 3)) * 2;
+            bf16x8 pf = tr_pair(pcol, pcol + 4 * PROW);
+            bf16x8 sf = tr_pair(scol, scol + 4 * PROW);
+            // A operands: dO^T / Q^T rows c
+            const int roff = irow * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                bf16x8 dof = tr_pair(sDO + roff + ct * 32, sDO + roff + ct * 32 + 4 * ROW);
-                bf16x8 qf = tr_pair(sQ + roff + ct * 32, sQ + roff + ct * 32 + 4 * ROW);
+                bf16x8 dof = tr_pair(sB + roff + ct * 32, sB + roff + ct * 32 + 4 * ROW);
+                bf16x8 qf = tr_pair(sA + roff + ct * 32, sA + roff + ct * 32 + 4 * ROW);
                 av[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, av[ct], 0, 0, 0);
                 ak[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[ct], 0, 0, 0);
             }
@@ -355,7 +362,7 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
     const int Lp = T * 16;
     int nw = T;
     if (nw > 8) nw = 8;
-    const size_t lds = 4 * (size_t)Lp * ROW + 2 * (size_t)Lp * (Lp * 2 + 32) + 192 * sizeof(float);
+    const size_t lds = 2 * (size_t)Lp * ROW + 2 * (size_t)Lp * (Lp * 2 + 32) + 192 * sizeof(float);
     const float scale = 0.125f;
     hipStream_t s = (hipStream_t)stream;
     CeProfScope prof(CE_PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (8.0 * D), s);
