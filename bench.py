@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 44.10e9        # ViT-B/32 fwd+bwd, K=1, no patch-conv dgrad
+TEXT_FLOP_PER_PAIR = 3 * 2 * 2.9798e9   # text tower's share of it (2.9798 GMAC/caption fwd)
 PEAK_BF16 = 2.5e15             # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 
@@ -39,6 +40,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU image batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dense-text", action="store_true",
+                    help="run the text tower on all 77 positions of every caption (default: live tokens SOT..EOT only; "
+                         "the default run also reports this dense variant as config.dense_text)")
+    ap.add_argument("--fresh-captions", action="store_true",
+                    help="hand the model a NEW caption tensor every step (forces the per-batch length read-back)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run both towers on one stream (the default overlaps them on two)")
     return ap.parse_args()
@@ -135,29 +141,51 @@ def main():
     txt = S.synthetic_tokens(B, 77, 49408, seed=999 + rank).to(dev)
     yi, yt, ip = D.global_labels(B, 1, 0, True, device=dev, rank_=rank)
 
+    if args.dense_text:
+        model.pack_text = False
+
     def step():
-        return train_step(model, crit, opt, img, txt, yi, yt, ip, grad_sync=sync)
+        t = txt.clone() if args.fresh_captions else txt
+        return train_step(model, crit, opt, img, t, yi, yt, ip, grad_sync=sync)
+
+    def timed(nsteps):
+        if W > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            out = step()
+        torch.cuda.synchronize()
+        if W > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if W > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt, out
 
     for _ in range(args.warmup):
         ld = step()
-    if W > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ld = step()
-    torch.cuda.synchronize()
-    if W > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if W > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    dt, ld = timed(args.steps)
     loss = float(sum(v.detach() for v in ld.values()))
     log(f"timed region: {ms_per_step_tmp(dt, args.steps):.2f} ms/step")
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = B * W * args.steps / dt
+    # text rows the tower actually ran on (live tokens SOT..EOT) vs the dense [B, 77] layout
+    lens = (txt.argmax(dim=-1) + 1).sum().item()
+    live_frac = 1.0 if args.dense_text else lens / float(B * 77)
+    dense = None
+    if not args.dense_text:      # the same step with every caption padded out to 77 rows, for comparison
+        model.pack_text = False
+        nd = max(5, args.steps // 2)
+        for _ in range(2):
+            step()
+        dtd, _ = timed(nd)
+        model.pack_text = True
+        dense = {"ms_per_step": round(dtd / nd * 1e3, 3), "value": round(B * W * nd / dtd, 2), "steps": nd}
+        log(f"dense-text variant: {dense['ms_per_step']:.2f} ms/step")
+        step()
 
     roof = None
     if not args.no_roofline:     # every rank runs the instrumented steps (they contain collectives); rank 0 reports
@@ -199,7 +227,11 @@ def main():
         roof = {"bound": "mfma" if mfma else "hbm", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
                 "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
+                # nominal = SURVEY 8(d)'s 44.10 GFLOP/pair (all 77 text positions); executed = FLOPs actually issued
+                # (text-tower GEMM work scales with the live-row fraction)
                 "step_frac_of_bf16_peak": round(pairs_per_s / W * FLOP_PER_PAIR / PEAK_BF16, 4),
+                "step_frac_of_bf16_peak_executed": round(
+                    pairs_per_s / W * (FLOP_PER_PAIR - TEXT_FLOP_PER_PAIR * (1.0 - live_frac)) / PEAK_BF16, 4),
                 "classes": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
     if W > 1:
         dist.barrier()
@@ -216,7 +248,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=1, InfoNCE only, full train step "
                                    "(fwd+bwd+clip_grad_norm+Adam), random-init weights" % B,
-                       "global_batch": B * W, "parallelism": "dp%d" % W, "loss": round(loss, 4)},
+                       "global_batch": B * W, "parallelism": "dp%d" % W, "loss": round(loss, 4),
+                       "captions": "SOT + U[8,75] random ids + EOT, zero-padded to 77 (SURVEY 8(d) c2)",
+                       "text_rows": ("all 77 positions" if args.dense_text else
+                                     "live tokens SOT..EOT only: %.1f%% of B*77 rows (identical results, see DESIGN.md)"
+                                     % (100.0 * live_frac)),
+                       "fresh_captions_every_step": bool(args.fresh_captions),
+                       "dense_text": dense},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

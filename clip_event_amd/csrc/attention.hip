@@ -52,7 +52,8 @@ __device__ __forceinline__ void stage_head(char* dst, const bf16_t* src, long ld
 
 template <int T>  // T = Lp / 16 key tiles (Lp = L rounded up to 32)
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
-                                                       long ldo, float* __restrict__ lse, int L, int H, int D,
+                                                       long ldo, float* __restrict__ lse,
+                                                       const int* __restrict__ cu, int Lmax, int H, int D,
                                                        int causal, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = T * 16;
@@ -61,10 +62,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
+    // packed (variable-length) batches: sample b owns rows cu[b] .. cu[b+1]-1; dense: b*Lmax .. +Lmax-1
+    const long row0 = cu ? (long)cu[b] : (long)b * Lmax;
+    const int L = cu ? min(cu[b + 1] - cu[b], Lmax) : Lmax;
+    if (L <= 0) return;
+    const int Tl = ((L + 31) >> 5) << 1;            // live 16-key tiles (even), block-uniform
+    const bf16_t* base = qkv + row0 * ld + h * HD;
 
-    stage_head(sK, base + D, ld, L, Lp, tid, blockDim.x);
-    stage_head(sV, base + 2 * D, ld, L, Lp, tid, blockDim.x);
+    stage_head(sK, base + D, ld, L, Tl * 16, tid, blockDim.x);
+    stage_head(sV, base + 2 * D, ld, L, Tl * 16, tid, blockDim.x);
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
@@ -80,10 +86,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < Tl) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                }
             }
         }
         // lane holds S^T[j = 16t + 4g + r][i]
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sidx = 0; sidx < T / 2; ++sidx) {
+            if (2 * sidx >= Tl) continue;
             bf16x8 pf = pack8(s[2 * sidx], s[2 * sidx + 1]);
             const char* vrow = sV + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
@@ -125,13 +134,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
         }
         if (i < L) {
             const float inv = 1.0f / sum;
-            bf16_t* orow = o + ((long)b * L + i) * ldo + h * HD + 4 * g;
+            bf16_t* orow = o + (row0 + i) * ldo + h * HD + 4 * g;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 u32x2 pk = {pack_bf2(acc[ct][0] * inv, acc[ct][1] * inv), pack_bf2(acc[ct][2] * inv, acc[ct][3] * inv)};
                 *reinterpret_cast<u32x2*>(orow + ct * 16) = pk;
             }
-            if (g == 0) lse[((long)b * H + h) * L + i] = mx + __logf(sum);
+            if (g == 0) lse[((long)b * H + h) * Lmax + i] = mx + __logf(sum);
         }
     }
 }
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ o, long ldo,
                                                        const bf16_t* __restrict__ dout, long lddo,
                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                       long lddq, float* __restrict__ bias_grad, int L, int H, int D,
+                                                       long lddq, float* __restrict__ bias_grad,
+                                                       const int* __restrict__ cu, int Lmax, int H, int D,
                                                        int causal, float scale) {
     // LDS: two [Lp][64] operand images (K,V in phase 1; re-filled with Q,dO for phase 2) + the P / dS images
     // [query i][key j] + 192 floats.  74 KiB at L=77 (two workgroups per CU), 41 KiB at L=50 (three).
@@ -156,19 +166,24 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
-    const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
-    const bf16_t* ob = o + (long)b * L * ldo + h * HD;
-    bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
+    const long row0 = cu ? (long)cu[b] : (long)b * Lmax;         // packed batches: see attn_fwd_kernel
+    const int L = cu ? min(cu[b + 1] - cu[b], Lmax) : Lmax;
+    if (L <= 0) return;
+    const int Tl = ((L + 31) >> 5) << 1;                         // live 16-row tiles (even), block-uniform
+    const int Ll = Tl * 16;
+    const bf16_t* base = qkv + row0 * ld + h * HD;
+    const bf16_t* dob = dout + row0 * lddo + h * HD;
+    const bf16_t* ob = o + row0 * ldo + h * HD;
+    bf16_t* dbase = dqkv + row0 * lddq + h * HD;
 
     for (int i = tid; i < 192; i += blockDim.x) csum[i] = 0.f;   // the workgroup may have fewer than 192 threads
-    stage_head(sA, base + D, ld, L, Lp, tid, blockDim.x);        // K
-    stage_head(sB, base + 2 * D, ld, L, Lp, tid, blockDim.x);    // V
+    stage_head(sA, base + D, ld, L, Ll, tid, blockDim.x);        // K
+    stage_head(sB, base + 2 * D, ld, L, Ll, tid, blockDim.x);    // V
     __syncthreads();
 
     const int li = lane & 15, g = lane >> 4;
     // ---------------- phase 1: per 16-query strip ----------------
-    for (int strip = wave; strip < T; strip += nw) {
+    for (int strip = wave; strip < Tl; strip += nw) {
         const int i = strip * 16 + li;
         const bool iok = i < L;
         const int iq = min(i, L - 1);
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
             dl += __shfl_xor(dl, 16, 64);
             dl += __shfl_xor(dl, 32, 64);
         }
-        const float lsei = lse[((long)b * H + h) * L + iq];
+        const float lsei = lse[((long)b * H + h) * Lmax + iq];
         bf16x8 qf[2], df[2];       // B operands: rows of Q and dO straight from global (only this wave needs them)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         for (int t = 0; t < T; ++t) {
             p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t >= Tl) continue;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(sA + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sidx = 0; sidx < T / 2; ++sidx) {
+            if (2 * sidx >= Tl) continue;
             bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
             const char* krow = sA + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
@@ -253,8 +270,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         }
     }
     __syncthreads();                                             // K, V no longer needed; P / dS images complete
-    stage_head(sA, base, ld, L, Lp, tid, blockDim.x);            // Q
-    stage_head(sB, dob, lddo, L, Lp, tid, blockDim.x);           // dO
+    stage_head(sA, base, ld, L, Ll, tid, blockDim.x);            // Q
+    stage_head(sB, dob, lddo, L, Ll, tid, blockDim.x);           // dO
     __syncthreads();
     // ---------------- phase 2: per 16-key tile ----------------
     const int nkt = (L + 15) >> 4;
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         }
 #pragma unroll
         for (int sidx = 0; sidx < T / 2; ++sidx) {
+            if (2 * sidx >= Tl) continue;
             // contraction i = 32s + 8g + jj (natural order) for both operands
             const int irow = 32 * sidx + 8 * g + (li >> 2);
             // B operands: P[i][j], dS[i][j] = 8 consecutive queries of key column j -> transposed reads of the [i][j] images
@@ -330,8 +348,8 @@ int tiles_for(int L) { return ((L + 31) / 32) * 2; }
         default: CE_CHECK_ARG(false, "attention: sequence length %d not supported (max 128)", L); \
     }
 
-extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, int B, int L, int H,
-                                int causal, void* stream) {
+extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, const int* cu_seqlens, int B,
+                                int L, int H, int causal, void* stream) {
     CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_fwd: empty problem");
     CE_CHECK_ARG(ld % 8 == 0 && ldo % 4 == 0, "ce_attention_fwd: ld must be a multiple of 8, ldo of 4");
     const int D = H * HD;
@@ -345,7 +363,7 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
     CeProfScope prof(CE_PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (4.0 * D), s);
 #define CALL(TT)                                                                                              \
     hipLaunchKernelGGL(attn_fwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld, (bf16_t*)o, ldo, \
-                       lse, L, H, D, causal, scale)
+                       lse, cu_seqlens, L, H, D, causal, scale)
     ATTN_DISPATCH(T, CALL);
 #undef CALL
     CE_LAUNCH_CHECK();
@@ -353,8 +371,8 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
 }
 
 extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
-                                const float* lse, void* dqkv, long lddq, float* bias_grad, int B, int L, int H,
-                                int causal, void* stream) {
+                                const float* lse, void* dqkv, long lddq, float* bias_grad, const int* cu_seqlens, int B,
+                                int L, int H, int causal, void* stream) {
     CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_bwd: empty problem");
     CE_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0, "ce_attention_bwd: bad leading dimension");
     const int D = H * HD;
@@ -375,8 +393,8 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
             attr = true;                                                                                           \
         }                                                                                                          \
         hipLaunchKernelGGL(attn_bwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld,        \
-                           (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, \
-                           causal, scale);                                                                                 \
+                           (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, cu_seqlens, L, \
+                           H, D, causal, scale);                                                                           \
     } while (0)
     ATTN_DISPATCH(T, CALL);
 #undef CALL

@@ -71,32 +71,56 @@ __global__ void vision_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t
     }
 }
 
-__global__ void token_embed_kernel(const long* __restrict__ ids, const float* __restrict__ table,
-                                   const float* __restrict__ pos, float* __restrict__ x0, long rows, int Ltok, int D,
-                                   int vocab) {
+// `src` (nullable): packed batch, output row r is element src[r] of the flattened [n, Ltok] id matrix
+__global__ void token_embed_kernel(const long* __restrict__ ids, const int* __restrict__ src,
+                                   const float* __restrict__ table, const float* __restrict__ pos,
+                                   float* __restrict__ x0, long rows, int Ltok, int D, int vocab) {
     const long total = rows * (D / 4);
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % (D / 4)) * 4;
         const long row = idx / (D / 4);
-        long id = ids[row];
+        const long e = src ? (long)src[row] : row;
+        long id = ids[e];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // ids are validated on the host; clamp keeps the access in bounds
         f32x4 v = *reinterpret_cast<const f32x4*>(table + id * D + c);
-        v += *reinterpret_cast<const f32x4*>(pos + (long)(row % Ltok) * D + c);
+        v += *reinterpret_cast<const f32x4*>(pos + (long)(e % Ltok) * D + c);
         *reinterpret_cast<f32x4*>(x0 + row * D + c) = v;
     }
 }
 
 // dtable[ids[row], :] += dx0[row, :]   one wave-instruction = 256 contiguous bytes of one row
-__global__ void token_embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dx0,
-                                       float* __restrict__ dtable, long rows, int D, int vocab) {
+// Exact zeros are skipped: under the causal mask the rows after a caption's EOT receive no gradient at all, and
+// they all carry the padding id 0 -- without the skip they serialise thousands of same-address atomics.
+__global__ void token_embed_bwd_kernel(const long* __restrict__ ids, const int* __restrict__ src,
+                                       const float* __restrict__ dx0, float* __restrict__ dtable, long rows, int D,
+                                       int vocab) {
     const long total = rows * D;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long row = idx / D;
         const int c = (int)(idx % D);
-        long id = ids[row];
+        const float v = dx0[idx];
+        if (v == 0.f) continue;
+        long id = ids[src ? (long)src[row] : row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-        atomicAdd(dtable + id * D + c, dx0[idx]);
+        atomicAdd(dtable + id * D + c, v);
     }
+}
+
+// Positional-embedding gradient of a packed batch: dpos[t, :] += sum over the samples b longer than t of
+// dx0[cu[b] + t, :].  grid = (Ltok, SPLIT): each block sums every SPLIT-th sample, D/4 threads x 4 columns.
+__global__ void pos_embed_bwd_packed_kernel(const float* __restrict__ dx0, const int* __restrict__ cu,
+                                            float* __restrict__ dpos, int n, int D) {
+    const int t = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    if (c >= D) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = blockIdx.y; b < n; b += gridDim.y) {
+        const int r0 = cu[b], len = cu[b + 1] - r0;         // block-uniform
+        if (t < len) acc += *reinterpret_cast<const f32x4*>(dx0 + (long)(r0 + t) * D + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (acc[e] != 0.f) atomicAdd(dpos + (long)t * D + c + e, acc[e]);
 }
 
 // out[t, c] (+)= sum_b x[b, t, c]  over `B` slabs of `slab` floats, rows [row0, row0+nrows) of each slab
@@ -258,20 +282,31 @@ extern "C" int ce_vision_assemble_bwd(const float* dx0, void* dpatch, int B, int
     return 0;
 }
 
-extern "C" int ce_token_embed(const int64_t* ids, const float* table, const float* pos, float* x0, long rows,
-                              int tokens, int D, int vocab, void* stream) {
+extern "C" int ce_token_embed(const int64_t* ids, const int* src_rows, const float* table, const float* pos, float* x0,
+                              long rows, int tokens, int D, int vocab, void* stream) {
     CE_CHECK_ARG(rows > 0 && tokens > 0 && D % 4 == 0 && vocab > 0, "ce_token_embed: bad shape");
     hipLaunchKernelGGL(token_embed_kernel, dim3(grid_for(rows * (D / 4))), dim3(256), 0, (hipStream_t)stream,
-                       (const long*)ids, table, pos, x0, rows, tokens, D, vocab);
+                       (const long*)ids, src_rows, table, pos, x0, rows, tokens, D, vocab);
     CE_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int ce_token_embed_bwd(const int64_t* ids, const float* dx0, float* dtable, long rows, int D, int vocab,
-                                  void* stream) {
+extern "C" int ce_token_embed_bwd(const int64_t* ids, const int* src_rows, const float* dx0, float* dtable, long rows,
+                                  int D, int vocab, void* stream) {
     CE_CHECK_ARG(rows > 0 && D > 0 && vocab > 0, "ce_token_embed_bwd: bad shape");
     hipLaunchKernelGGL(token_embed_bwd_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
-                       (const long*)ids, dx0, dtable, rows, D, vocab);
+                       (const long*)ids, src_rows, dx0, dtable, rows, D, vocab);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_pos_embed_bwd_packed(const float* dx0, const int* cu_seqlens, float* dpos, int n, int tokens, int D,
+                                       void* stream) {
+    CE_CHECK_ARG(n > 0 && tokens > 0 && D > 0 && D % 4 == 0 && D <= 4096 && cu_seqlens, "ce_pos_embed_bwd_packed: bad shape");
+    const int split = n < 8 ? n : 8;
+    const int threads = ((D / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(pos_embed_bwd_packed_kernel, dim3(tokens, split), dim3(threads), 0, (hipStream_t)stream, dx0,
+                       cu_seqlens, dpos, n, D);
     CE_LAUNCH_CHECK();
     return 0;
 }

@@ -82,9 +82,10 @@ struct Layout {
     size_t bytes;
 };
 
-void carve(const ce_tower_desc* d, int batch, void* ws, Layout& L) {
+// `rows` = activation rows the stash is laid out for: batch*tokens, or fewer for a packed (variable-length) batch
+void carve(const ce_tower_desc* d, int batch, size_t rows, void* ws, Layout& L) {
     Carver c(ws);
-    const size_t M = (size_t)batch * d->tokens, w = d->width;
+    const size_t M = rows, w = d->width;
     for (int l = 0; l < d->layers; ++l) {
         BlockStash& s = L.blk[l];
         s.x_mid = c.take<float>(M * w);
@@ -118,6 +119,12 @@ void carve(const ce_tower_desc* d, int batch, void* ws, Layout& L) {
     L.bytes = (c.off + 255) & ~size_t(255);
 }
 
+int check_rows(const ce_tower_desc* d, int batch, int rows, const int* cu) {
+    CE_CHECK_ARG(rows > 0 && (long)rows <= (long)batch * d->tokens, "tower: rows=%d outside 1..batch*tokens", rows);
+    CE_CHECK_ARG(cu || rows == batch * d->tokens, "tower: a dense batch has batch*tokens rows (got %d)", rows);
+    return 0;
+}
+
 int check_desc(const ce_tower_desc* d, int batch) {
     CE_CHECK_ARG(d && d->blocks, "tower: null descriptor");
     CE_CHECK_ARG(d->layers > 0 && d->layers <= Layout::MAX_LAYERS, "tower: layers=%d out of range", d->layers);
@@ -138,17 +145,18 @@ int check_desc(const ce_tower_desc* d, int batch) {
 extern "C" size_t ce_tower_workspace_bytes(const ce_tower_desc* d, int batch) {
     if (check_desc(d, batch) != 0) return 0;
     Layout L;
-    carve(d, batch, nullptr, L);
+    carve(d, batch, (size_t)batch * d->tokens, nullptr, L);
     return L.bytes;
 }
 
-extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* x_out,
-                                const int* sel_rows, void* stream) {
+extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
+                                void* workspace, float* x_out, const int* sel_rows, void* stream) {
     TRY(check_desc(d, batch));
+    TRY(check_rows(d, batch, rows, cu_seqlens));
     CE_CHECK_ARG(x0 && workspace && x_out, "ce_tower_forward: null buffer");
     Layout L;
-    carve(d, batch, workspace, L);
-    const int M = batch * d->tokens, w = d->width;
+    carve(d, batch, rows, workspace, L);
+    const int M = rows, w = d->width;
     const float* x = x0;
     for (int l = 0; l < d->layers; ++l) {
         const ce_block_params& p = d->blocks[l];
@@ -157,7 +165,7 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, const float* 
         TRY(ce_layernorm_fwd(x, w, nullptr, p.ln1_w, p.ln1_b, s.h1, w, 0, s.mean1, s.rstd1, M, w, 1e-5f, stream));
         TRY(ce_gemm_nt(s.h1, w, p.w_qkv, w, M, 3 * w, w, CE_EPI_BIAS_BF16, p.b_qkv, nullptr, 0, s.qkv, 3 * w, nullptr, 0,
                        nullptr, 0, stream));
-        TRY(ce_attention_fwd(s.qkv, 3 * w, s.o, w, s.lse, batch, d->tokens, d->heads, d->causal, stream));
+        TRY(ce_attention_fwd(s.qkv, 3 * w, s.o, w, s.lse, cu_seqlens, batch, d->tokens, d->heads, d->causal, stream));
         if (sel_rows && l + 1 == d->layers) {
             // pruned last block: only the selected token of each sample feeds the head, so the out-projection
             // and the MLP run on `batch` rows (75 % of this block's GEMM work is never needed)
@@ -185,13 +193,14 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, const float* 
     return 0;
 }
 
-extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx,
-                                 const int* sel_rows, const float* dx_sel, void* stream) {
+extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
+                                 void* workspace, float* dx, const int* sel_rows, const float* dx_sel, void* stream) {
     TRY(check_desc(d, batch));
+    TRY(check_rows(d, batch, rows, cu_seqlens));
     CE_CHECK_ARG(x0 && workspace && dx, "ce_tower_backward: null buffer");
     Layout L;
-    carve(d, batch, workspace, L);
-    const int M = batch * d->tokens, w = d->width;
+    carve(d, batch, rows, workspace, L);
+    const int M = rows, w = d->width;
     // Per block l (buffer set q = l & 1): dxb_a = bf16 gradient at the block output (operand of mlp.c_proj's
     // dgrad/wgrad, written by block l+1's ln_1 backward), dxb_b = bf16 gradient at x_mid (attn.out_proj), da,
     // dqkv.  They stay alive until the block's four weight gradients have run as ONE grouped launch on the side
@@ -231,7 +240,7 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         // attention sees dO only on the selected rows
         if (hipMemsetAsync(L.d_o, 0, (size_t)M * w * 2, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
         TRY(ce_copy_rows(L.dos, w * 2L, nullptr, L.d_o, w * 2L, sel_rows, Bn, w * 2, stream));
-        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv[q], 3 * w, p.g_b_qkv, batch, d->tokens, d->heads,
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv[q], 3 * w, p.g_b_qkv, cu_seqlens, batch, d->tokens, d->heads,
                              d->causal, stream));
         mark_ready(l);
         {
@@ -278,7 +287,7 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, const float*
         TRY(ce_gemm_nt(dxb_b, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
                        stream));                                                  // d_o = dx Wo
         // ---- attention core ----
-        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, p.g_b_qkv, batch, d->tokens, d->heads,
+        TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, p.g_b_qkv, cu_seqlens, batch, d->tokens, d->heads,
                              d->causal, stream));
         // ---- the four weight gradients of this block, one launch, on the side stream ----
         mark_ready(l);

@@ -9,8 +9,10 @@ the node on the autograd tape.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from ctypes import c_float, c_int, c_long, c_void_p
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -28,6 +30,59 @@ def _tower_workspace(model, desc, batch: int, tag: str):
         raise RuntimeError("ce_tower_workspace_bytes: " + lib().ce_last_error().decode())
     buf = model._pool.take(tag, int(nbytes), model._flat.device)
     return _Lease(model._pool, tag, buf)
+
+
+def _publish_to_main(ctx):
+    """Parameter gradients are written as side effects on the stream this backward ran on (the tower's side
+    stream); make the stream the step was issued from wait for them, so that an optimiser / clip_grad_norm_ /
+    all-reduce enqueued there after ``backward()`` sees complete gradients."""
+    ms = ctx.main_stream
+    if ms is not None:
+        cur = torch.cuda.current_stream()
+        if cur != ms:
+            ms.wait_stream(cur)
+
+
+class TextPacking:
+    """Row layout of one caption batch in the text tower.  ``cu is None``: dense, every caption owns
+    ``context_length`` rows.  Otherwise only the live tokens (SOT .. EOT) are rows: ``cu`` int32 [n+1] prefix sums,
+    ``src`` int32 [rows] flat index into the [n, T] id matrix, ``sel`` int32 [n] = each caption's EOT row."""
+    __slots__ = ("rows", "cu", "src", "sel", "_keep")
+
+    def __init__(self, rows, cu, src, sel, keep=None):
+        self.rows, self.cu, self.src, self.sel, self._keep = rows, cu, src, sel, keep
+
+
+def text_packing(model, text) -> TextPacking:
+    """Drop the rows after each caption's EOT (model_clip.py:415 takes the feature AT the EOT; with the causal mask of
+    model_clip.py:377-384 later rows can reach neither that feature nor any gradient, so the result is unchanged).
+    The lengths have to reach the host (they size the launches): one 4*n-byte read-back per NEW token tensor; the
+    layout of a tensor seen before (same object, same version) is reused."""
+    cl, s = lib(), stream()
+    n, T = text.shape
+    dev = text.device
+    cache = getattr(model, "_pack_cache", None)
+    if cache is not None and cache[0]() is text and cache[1] == text._version and cache[2] == model.pack_text:
+        return cache[3]
+    eot = _empty((n,), torch.int32, dev)
+    check(cl.ce_eot_rows(ptr(text), ptr(eot), c_long(n), c_int(T), s), "ce_eot_rows")
+    if not model.pack_text:
+        pk = TextPacking(n * T, None, None, eot)
+    else:
+        flat = eot.cpu().numpy().astype(np.int64)                       # host sync on this stream only
+        lens = flat - np.arange(n, dtype=np.int64) * T + 1
+        cu = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=cu[1:])
+        R = int(cu[-1])
+        src = np.repeat(np.arange(n, dtype=np.int64) * T - cu[:-1], lens) + np.arange(R, dtype=np.int64)
+        meta = torch.empty(2 * n + 1 + R, dtype=torch.int32, pin_memory=True)
+        meta.numpy()[: n + 1] = cu
+        meta.numpy()[n + 1: 2 * n + 1] = cu[1:] - 1
+        meta.numpy()[2 * n + 1:] = src
+        meta_d = meta.to(dev, non_blocking=True)
+        pk = TextPacking(R, meta_d[: n + 1], meta_d[2 * n + 1:], meta_d[n + 1: 2 * n + 1], keep=(meta, meta_d))
+    model._pack_cache = (weakref.ref(text), text._version, model.pack_text, pk)
+    return pk
 
 
 def _empty(shape, dtype, dev):
@@ -74,7 +129,8 @@ class EncodeImageFn(torch.autograd.Function):
             rows = (torch.arange(B, device=dev, dtype=torch.int32) * T)
             n = B
         xN = _empty((n, D), torch.float32, dev)
-        check(cl.ce_tower_forward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(xN), ptr(rows), s),
+        check(cl.ce_tower_forward(ctypes.byref(model._vdesc), c_int(B), c_int(M), None, ptr(x0), ptr(lease.buf), ptr(xN),
+                                  ptr(rows), s),
               "ce_tower_forward(vision)")
         hpost = _empty((n, D), torch.bfloat16, dev)
         mean_post, rstd_post = _empty((n,), torch.float32, dev), _empty((n,), torch.float32, dev)
@@ -87,6 +143,7 @@ class EncodeImageFn(torch.autograd.Function):
                             None, None, c_long(0), ptr(feat), c_long(E), None, c_long(0), None, c_long(0), s),
               "ce_gemm_nt(visual.proj)")
         ctx.model, ctx.lease, ctx.use_grid, ctx.B = model, lease, use_grid, B
+        ctx.main_stream = getattr(model, "_main_stream", None)
         ctx.saved = (patches, xpre, mean_pre, rstd_pre, x0, xN, rows, hpost, mean_post, rstd_post)
         return feat.view(B, T, E) if use_grid else feat
 
@@ -122,12 +179,13 @@ class EncodeImageFn(torch.autograd.Function):
                                   c_int(D), s), "ce_layernorm_bwd(ln_post)")
         if rows is None:
             dx = dxn
-            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), None, None, s),
+            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), c_int(M), None, ptr(x0), ptr(lease.buf),
+                                       ptr(dx), None, None, s),
                   "ce_tower_backward(vision)")
         else:
             dx = _empty((M, D), torch.float32, dev)
-            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), ptr(x0), ptr(lease.buf), ptr(dx), ptr(rows),
-                                       ptr(dxn), s), "ce_tower_backward(vision)")
+            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), c_int(M), None, ptr(x0), ptr(lease.buf),
+                                       ptr(dx), ptr(rows), ptr(dxn), s), "ce_tower_backward(vision)")
         lease.release()
         # ln_pre: x0 = LN(xpre)
         dxpre = _empty((M, D), torch.float32, dev)
@@ -148,6 +206,7 @@ class EncodeImageFn(torch.autograd.Function):
               "ce_gemm_tn(conv1)")
         if model.grad_sync is not None:
             model.grad_sync(model, "visual")
+        _publish_to_main(ctx)
         return None, None, None, None
 
 
@@ -167,17 +226,17 @@ class EncodeTextFn(torch.autograd.Function):
         if T != model.context_length:
             raise RuntimeError(f"expected {model.context_length} tokens per row, got {T}")
         D, E = model.transformer.width, model.embed_dim
-        M = n * T
         P = model._pmap
+        pk = text_packing(model, text)
+        M = pk.rows                                        # activation rows: live tokens only when packed
         x0 = _empty((M, D), torch.float32, dev)
-        check(cl.ce_token_embed(ptr(text), ptr(P["token_embedding.weight"]), ptr(P["positional_embedding"]), ptr(x0),
-                                c_long(M), c_int(T), c_int(D), c_int(model.vocab_size), s), "ce_token_embed")
+        check(cl.ce_token_embed(ptr(text), ptr(pk.src), ptr(P["token_embedding.weight"]), ptr(P["positional_embedding"]),
+                                ptr(x0), c_long(M), c_int(T), c_int(D), c_int(model.vocab_size), s), "ce_token_embed")
         lease = _tower_workspace(model, model._tdesc, n, "text")
-        rows = _empty((n,), torch.int32, dev)              # EOT row of each caption (argmax token id, model_clip.py:415)
-        check(cl.ce_eot_rows(ptr(text), ptr(rows), c_long(n), c_int(T), s), "ce_eot_rows")
+        rows = pk.sel                                      # EOT row of each caption (argmax token id, model_clip.py:415)
         xN = _empty((n, D), torch.float32, dev)            # pruned last block: only the EOT rows are produced
-        check(cl.ce_tower_forward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(xN), ptr(rows), s),
-              "ce_tower_forward(text)")
+        check(cl.ce_tower_forward(ctypes.byref(model._tdesc), c_int(n), c_int(M), ptr(pk.cu), ptr(x0), ptr(lease.buf),
+                                  ptr(xN), ptr(rows), s), "ce_tower_forward(text)")
         hfin = _empty((n, D), torch.bfloat16, dev)
         mean_f, rstd_f = _empty((n,), torch.float32, dev), _empty((n,), torch.float32, dev)
         check(cl.ce_layernorm_fwd(ptr(xN), c_long(D), None, ptr(P["ln_final.weight"]), ptr(P["ln_final.bias"]),
@@ -189,7 +248,8 @@ class EncodeTextFn(torch.autograd.Function):
                             None, None, c_long(0), ptr(feat), c_long(E), None, c_long(0), None, c_long(0), s),
               "ce_gemm_nt(text_projection)")
         ctx.model, ctx.lease, ctx.n = model, lease, n
-        ctx.saved = (text, x0, xN, rows, hfin, mean_f, rstd_f)
+        ctx.main_stream = getattr(model, "_main_stream", None)
+        ctx.saved = (text, x0, xN, pk, hfin, mean_f, rstd_f)
         return feat
 
     @staticmethod
@@ -198,10 +258,10 @@ class EncodeTextFn(torch.autograd.Function):
         if lease.buf is None:
             raise RuntimeError("backward through encode_text a second time: the activation stash was released")
         cl, s = lib(), stream()
-        text, x0, xN, rows, hfin, mean_f, rstd_f = ctx.saved
+        text, x0, xN, pk, hfin, mean_f, rstd_f = ctx.saved
         dev = model._flat.device
         T, D, E = model.context_length, model.transformer.width, model.embed_dim
-        M = n * T
+        M, rows = pk.rows, pk.sel
         model._attach_grads()
         P, G = model._pmap, model._gview
         dfeat = _f32(dfeat)
@@ -219,15 +279,20 @@ class EncodeTextFn(torch.autograd.Function):
                                   ptr(G("ln_final.weight")), ptr(G("ln_final.bias")), None, c_int(n), c_int(D), s),
               "ce_layernorm_bwd(ln_final)")
         dx = _empty((M, D), torch.float32, dev)
-        check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), ptr(x0), ptr(lease.buf), ptr(dx), ptr(rows),
-                                   ptr(dxn), s), "ce_tower_backward(text)")
+        check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), c_int(M), ptr(pk.cu), ptr(x0), ptr(lease.buf),
+                                   ptr(dx), ptr(rows), ptr(dxn), s), "ce_tower_backward(text)")
         lease.release()
-        check(cl.ce_batch_reduce(ptr(dx), ptr(G("positional_embedding")), c_int(n), c_long(T * D), c_long(T * D),
-                                 c_int(1), s), "ce_batch_reduce(text pos)")
-        check(cl.ce_token_embed_bwd(ptr(text), ptr(dx), ptr(G("token_embedding.weight")), c_long(M), c_int(D),
+        if pk.cu is None:
+            check(cl.ce_batch_reduce(ptr(dx), ptr(G("positional_embedding")), c_int(n), c_long(T * D), c_long(T * D),
+                                     c_int(1), s), "ce_batch_reduce(text pos)")
+        else:
+            check(cl.ce_pos_embed_bwd_packed(ptr(dx), ptr(pk.cu), ptr(G("positional_embedding")), c_int(n), c_int(T),
+                                             c_int(D), s), "ce_pos_embed_bwd_packed")
+        check(cl.ce_token_embed_bwd(ptr(text), ptr(pk.src), ptr(dx), ptr(G("token_embedding.weight")), c_long(M), c_int(D),
                                     c_int(model.vocab_size), s), "ce_token_embed_bwd")
         if model.grad_sync is not None:
             model.grad_sync(model, "text")
+        _publish_to_main(ctx)
         return None, None, None
 
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from ctypes import c_float, c_int, c_long, c_void_p
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -203,6 +204,9 @@ class CLIP(nn.Module):
         self._trigger = None
         self._versions = None
         self.grad_sync = None                     # optional callable(model, tower_name) for DP overlap
+        # text tower on the live tokens only (rows after a caption's EOT are dead under the causal mask); results
+        # are unchanged, see functional.text_packing.  CE_TEXT_PACK=0 keeps the dense [n, 77] layout.
+        self.pack_text = os.environ.get("CE_TEXT_PACK", "1") != "0"
 
     # ---- reference API -------------------------------------------------------------------
     def set_hyps(self, constrastive_overbatch=True, alignment=False, multiattention=False):
@@ -437,11 +441,13 @@ class CLIP(nn.Module):
         autograd engine replays each tower's backward on its forward stream, so the backward overlaps too."""
         self._ready()
         if not getattr(self, "tower_streams", True):
+            self._main_stream = None
             return self.encode_image(image), self.encode_text(text)
         if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != self._flat.device:
             self._side_streams = (torch.cuda.Stream(device=self._flat.device), torch.cuda.Stream(device=self._flat.device))
         s_img, s_txt = self._side_streams
         cur = torch.cuda.current_stream()
+        self._main_stream = cur
         s_img.wait_stream(cur)
         s_txt.wait_stream(cur)
         with torch.cuda.stream(s_img):

@@ -72,21 +72,23 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, rows=None, dx_in=None, dx_out
     return dx_out
 
 
-def attention_fwd(qkv: torch.Tensor, B: int, L: int, H: int, causal: bool):
-    """o, lse = attention(qkv[B*L, 3*H*64])."""
+def attention_fwd(qkv: torch.Tensor, B: int, L: int, H: int, causal: bool, cu_seqlens=None):
+    """o, lse = attention(qkv[B*L, 3*H*64]); ``cu_seqlens`` (int32 [B+1]) = packed variable-length batch."""
     assert qkv.dtype == torch.bfloat16
     o = torch.empty(qkv.shape[0], H * 64, device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty(B * H * L, device=qkv.device, dtype=torch.float32)
-    check(lib().ce_attention_fwd(ptr(qkv), c_long(qkv.stride(0)), ptr(o), c_long(o.stride(0)), ptr(lse), c_int(B),
-                                 c_int(L), c_int(H), c_int(1 if causal else 0), stream()), "ce_attention_fwd")
+    check(lib().ce_attention_fwd(ptr(qkv), c_long(qkv.stride(0)), ptr(o), c_long(o.stride(0)), ptr(lse),
+                                 ptr(cu_seqlens), c_int(B), c_int(L), c_int(H), c_int(1 if causal else 0), stream()),
+          "ce_attention_fwd")
     return o, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B: int, L: int, H: int, causal: bool, bias_grad=None):
+def attention_bwd(qkv, o, dout, lse, B: int, L: int, H: int, causal: bool, bias_grad=None, cu_seqlens=None):
     dqkv = torch.empty_like(qkv)
     check(lib().ce_attention_bwd(ptr(qkv), c_long(qkv.stride(0)), ptr(o), c_long(o.stride(0)), ptr(dout),
-                                 c_long(dout.stride(0)), ptr(lse), ptr(dqkv), c_long(dqkv.stride(0)), ptr(bias_grad), c_int(B), c_int(L),
-                                 c_int(H), c_int(1 if causal else 0), stream()), "ce_attention_bwd")
+                                 c_long(dout.stride(0)), ptr(lse), ptr(dqkv), c_long(dqkv.stride(0)), ptr(bias_grad),
+                                 ptr(cu_seqlens), c_int(B), c_int(L), c_int(H), c_int(1 if causal else 0), stream()),
+          "ce_attention_bwd")
     return dqkv
 
 

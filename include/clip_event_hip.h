@@ -90,13 +90,15 @@ int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const float* x, long
 /* Self-attention core on the packed in-projection output qkv[B*L, 3*H*64] (bf16; q | k | v column
  * blocks, head h at columns h*64): o[B*L, H*64] = softmax(q k^T / 8 + causal?) v, lse[B*H*L] (f32)
  * saved for the backward.  L <= 128.  Replaces the core of nn.MultiheadAttention as called at
- * model_clip.py:188 (mask from model_clip.py:377-384). */
-int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, int B, int L, int H, int causal,
-                     void* stream);
+ * model_clip.py:188 (mask from model_clip.py:377-384).
+ * cu_seqlens (int32 [B+1], nullable): variable-length batch, sample b owns rows cu_seqlens[b] ..
+ * cu_seqlens[b+1]-1 (at most L of them); NULL = dense, sample b owns rows b*L .. b*L+L-1.  lse stays [B,H,L]. */
+int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, const int* cu_seqlens, int B, int L,
+                     int H, int causal, void* stream);
 /* bias_grad (f32 [3*H*64], nullable) += column sums of dqkv (the in_proj bias gradient) */
 int ce_attention_bwd(const void* qkv, long ld, const void* o, long ldo, const void* dout, long lddo,
-                     const float* lse, void* dqkv, long lddq, float* bias_grad, int B, int L, int H, int causal,
-                     void* stream);
+                     const float* lse, void* dqkv, long lddq, float* bias_grad, const int* cu_seqlens, int B, int L,
+                     int H, int causal, void* stream);
 
 /* ---- input side, bookkeeping (embed.hip) ---- */
 /* image f32 [B,3,R,R] -> patch rows bf16 [B*(R/p)^2, k_padded], columns ordered (c, py, px) like the
@@ -107,11 +109,18 @@ int ce_im2col(const float* image, void* patches, int B, int resolution, int patc
 int ce_vision_assemble(const float* patch_out, const float* cls, const float* pos, float* x0, int B, int tokens,
                        int D, void* stream);
 int ce_vision_assemble_bwd(const float* dx0, void* dpatch, int B, int tokens, int D, void* stream);
-/* x0[r,:] = token_embedding[ids[r],:] + positional_embedding[r % tokens,:]  (model_clip.py:400-403) */
-int ce_token_embed(const int64_t* ids, const float* table, const float* pos, float* x0, long rows, int tokens,
-                   int D, int vocab, void* stream);
-int ce_token_embed_bwd(const int64_t* ids, const float* dx0, float* dtable, long rows, int D, int vocab,
-                       void* stream);
+/* x0[r,:] = token_embedding[ids[e],:] + positional_embedding[e % tokens,:], e = src_rows ? src_rows[r] : r
+ * (model_clip.py:400-403).  src_rows selects the LIVE tokens of a packed batch: under the causal mask
+ * (model_clip.py:377-384) the rows after a caption's EOT can influence neither its feature (taken at the EOT,
+ * model_clip.py:415) nor any gradient, so the text tower runs on the rows up to each EOT only.  The backward
+ * skips exact-zero gradient elements (they change nothing and would serialise on the padding id). */
+int ce_token_embed(const int64_t* ids, const int* src_rows, const float* table, const float* pos, float* x0, long rows,
+                   int tokens, int D, int vocab, void* stream);
+int ce_token_embed_bwd(const int64_t* ids, const int* src_rows, const float* dx0, float* dtable, long rows, int D,
+                       int vocab, void* stream);
+/* packed batch: dpos[t,:] += sum_{b : len_b > t} dx0[cu_seqlens[b] + t, :]   (cu_seqlens int32 [n+1]) */
+int ce_pos_embed_bwd_packed(const float* dx0, const int* cu_seqlens, float* dpos, int n, int tokens, int D,
+                            void* stream);
 /* out[i] (+)= sum_b x[b*slab + i], i < n  (positional / class embedding gradients) */
 int ce_batch_reduce(const float* x, float* out, int B, long slab, long n, int accumulate, void* stream);
 /* out[n] += sum_m x[m,n]  (bias gradients; atomics) */
@@ -189,14 +198,17 @@ size_t ce_tower_workspace_bytes(const ce_tower_desc* d, int batch);
  * sel_rows (int32 [B], flat row index of the ONE token per sample whose output is consumed: CLS for the
  * image tower, model_clip.py:256; EOT for the text tower, :415) selects the pruned mode: the last block's
  * out-projection and MLP run on those B rows only (the other rows of the last block's output are never read
- * by the reference either) and x_out is [B, width]. */
-int ce_tower_forward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* x_out,
-                     const int* sel_rows, void* stream);
+ * by the reference either) and x_out is [B, width].
+ * rows / cu_seqlens: a dense batch has rows = batch*tokens and cu_seqlens NULL; a packed batch (text tower,
+ * see ce_token_embed) has rows = cu_seqlens[batch] <= batch*tokens activation rows, sample b owning rows
+ * cu_seqlens[b] .. cu_seqlens[b+1]-1; sel_rows then index the packed rows. */
+int ce_tower_forward(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
+                     void* workspace, float* x_out, const int* sel_rows, void* stream);
 /* dx (f32 [B*T, width]) = gradient w.r.t. x0.  Full mode (sel_rows NULL): dx holds the gradient w.r.t. x_out on
  * entry (in place).  Pruned mode: dx_sel (f32 [B, width]) is the gradient w.r.t. the [B, width] output and dx is
  * output only.  Parameter gradients are accumulated into the g_* buffers. */
-int ce_tower_backward(const ce_tower_desc* d, int batch, const float* x0, void* workspace, float* dx,
-                      const int* sel_rows, const float* dx_sel, void* stream);
+int ce_tower_backward(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
+                      void* workspace, float* dx, const int* sel_rows, const float* dx_sel, void* stream);
 
 /* ---- optimal-transport alignment + region pooling (ot.hip) ---- */
 /* dist[b] = trace(C_b T_b): cosine cost between txt[b] (M rows) and img[b] (N rows), IPOT plan

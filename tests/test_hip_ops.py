@@ -172,6 +172,37 @@ def test_attention_fwd_bwd(B, L, H, causal):
         assert _report(f"attn {name} L={L}", dqkv[:, sl].float().cpu(), g[:, sl])[1] < 2e-2
 
 
+@pytest.mark.parametrize("lens,Lmax,H,causal", [([77, 10, 33, 1, 64, 77, 17], 77, 8, True), ([5, 50, 32, 31], 50, 3, False),
+                                                ([128, 3, 96, 97], 128, 2, True), ([16], 20, 1, True)])
+def test_attention_packed_variable_length(lens, Lmax, H, causal):
+    """Packed batch (cu_seqlens): each sample equals the dense kernel's / the fp32 reference's result on its own rows."""
+    from clip_event_amd import ops
+    rng = np.random.default_rng(sum(lens) + Lmax)
+    D, B = H * 64, len(lens)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    R = int(cu[-1])
+    qkv = _randn(rng, R, 3 * D).to(torch.bfloat16)
+    dout = _randn(rng, R, D).to(torch.bfloat16)
+    cu_d = torch.from_numpy(cu).to(DEV)
+    o, lse = ops.attention_fwd(qkv.to(DEV), B, Lmax, H, causal, cu_seqlens=cu_d)
+    bg = torch.zeros(3 * D, device=DEV)
+    dqkv = ops.attention_bwd(qkv.to(DEV), o, dout.to(DEV), lse, B, Lmax, H, causal, bias_grad=bg, cu_seqlens=cu_d)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(dqkv.float()).all())
+    lse = lse.cpu().view(B, H, Lmax)
+    bias_ref = torch.zeros(3 * D)
+    for b, ln in enumerate(lens):
+        sl = slice(int(cu[b]), int(cu[b + 1]))
+        x = qkv[sl].float().requires_grad_(True)
+        o_ref, lse_ref = _attn_ref(x, 1, ln, H, causal)
+        o_ref.backward(dout[sl].float())
+        assert _report(f"packed attn o len={ln}", o[sl].float().cpu(), o_ref.detach())[1] < 1e-2
+        assert _report("packed attn lse", lse[b, :, :ln], lse_ref.detach()[0])[0] < 1e-3
+        assert _report(f"packed attn dqkv len={ln}", dqkv[sl].float().cpu(), x.grad)[1] < 2e-2
+        bias_ref += x.grad.sum(0)
+    assert _report("packed attn in_proj bias grad", bg.cpu(), bias_ref)[1] < 2e-2
+
+
 @pytest.mark.parametrize("M,Nn,Kk", [(1000, 768, 512), (616, 512, 2048), (50, 64, 72), (12800, 768, 768), (77, 1536, 512)])
 def test_gemm_tn_fused_bias_grad(M, Nn, Kk):
     from ctypes import c_int, c_long

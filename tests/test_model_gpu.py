@@ -99,6 +99,38 @@ def test_tiny_features_bf16_oracle():
     assert tuple(fg.shape) == (G["B"], cfg.vision_tokens, cfg.embed_dim)
 
 
+def test_text_packing_matches_dense_layout():
+    """Dropping the rows after each EOT (functional.text_packing) changes neither the text features nor any
+    parameter gradient: same model, same inputs, packed vs dense [n, 77] layout."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 77, 512, 128, 2, 3)
+    m, _ = _mk(cfg, 5)
+    txt = S.synthetic_tokens(24, cfg.context_length, cfg.vocab_size, seed=11, min_len=1).to(DEV)
+    txt[3, :] = 0
+    txt[3, 0], txt[3, 1] = cfg.vocab_size - 2, cfg.vocab_size - 1          # empty caption: SOT EOT
+    w = torch.from_numpy(np.random.default_rng(3).standard_normal((24, cfg.embed_dim)).astype(np.float32)).to(DEV)
+    res = {}
+    for packed in (True, False):
+        m.pack_text = packed
+        m.zero_grad(set_to_none=True)
+        f = m.encode_text(txt)
+        (f * w).sum().backward()
+        torch.cuda.synchronize()
+        res[packed] = (f.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()
+                                          if p.grad is not None})
+    m.pack_text = True
+    assert _rel(res[True][0], res[False][0]) < 1e-5
+    worst = 0.0
+    for n, g in res[False][1].items():
+        if float(g.norm()) == 0.0:
+            assert float(res[True][1][n].norm()) == 0.0, n
+            continue
+        worst = max(worst, _rel(res[True][1][n], g))
+        assert _rel(res[True][1][n], g) < 2e-3, (n, _rel(res[True][1][n], g))
+    print(f"[packing] features rel {_rel(res[True][0], res[False][0]):.2e}, worst grad rel {worst:.2e}")
+
+
 def test_vitb32_b8_against_reference_golden():
     """BASELINE config 1 on the GPU: ViT-B/32, batch 8, caption-only InfoNCE, vs the imported reference."""
     from oracle import clip_oracle as O
