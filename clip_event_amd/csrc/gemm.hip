@@ -1043,13 +1043,36 @@ int nt_variant() {   // CE_GEMM_NT=128|256 forces a tile; default: pick per shap
     return v;
 }
 
-int force_tm() {   // CE_GEMM_TM=8|5 forces the 256-column kernel's tile height
-    static int v = -1;
-    if (v < 0) {
+int g_force_tm = -1;
+int force_tm() {   // CE_GEMM_TM / ce_gemm_nt_tune(): 3..8 = tile height (x32 rows) of the 256-column kernel, 32 = the
+                   // 160x256x32 two-workgroup kernel, 104 = 160x128 four-wave tile, 160 = three-stage ring; 0 = auto
+    if (g_force_tm < 0) {
         const char* e = getenv("CE_GEMM_TM");
-        v = e ? atoi(e) : 0;
+        g_force_tm = e ? atoi(e) : 0;
     }
-    return v;
+    return g_force_tm;
+}
+
+// Tile-variant cost model, fitted to tools/tune_nt.py sweeps (M 8k..20k, both towers' N/K; unit = 0.137 us at
+// K = 512, scales with K): one round of 32*TM-row tiles on the 256 CUs costs 28 + 10*TM (the K loop is
+// LDS-read bound: a fixed share for the 256-column B fragments plus TM A fragments per k-step); the
+// 160x256x32 kernel keeps two workgroups per CU: a co-resident pair costs 146, a lone one 78.
+inline long nt256_cost(long tiles, int tm) { return ((tiles + 255) / 256) * (28 + 10 * tm); }
+inline long nt32_cost(long tiles) {
+    const long n = (tiles + 255) / 256;
+    return (n / 2) * 146 + (n % 2) * 78;
+}
+
+template <int EPI, int TM>
+void launch_nt256(NTArgs& a, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, TM, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
+        attr = true;
+    }
+    a.tiles_m = ce_div_up(a.M, 32 * TM);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, TM, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
 }
 
 template <int EPI>
@@ -1058,10 +1081,6 @@ int launch_nt(NTArgs a, hipStream_t stream) {
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 8, 4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5, 4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2H_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt32_kernel<EPI>),
@@ -1077,29 +1096,40 @@ int launch_nt(NTArgs a, hipStream_t stream) {
     const bool want256 = force == 256 || (force == 0 && a.M >= 1024 && a.N >= 256);
     if (can256 && want256) {
         a.tiles_n = ce_div_up(a.N, N2_BN);
-        // pick the tile height by wave quantisation: cost ~ (rounds over 256 CUs) x (rows per tile)
-        const long t8 = (long)ce_div_up(a.M, 256) * a.tiles_n, t5 = (long)ce_div_up(a.M, 160) * a.tiles_n;
-        const long c8 = ((t8 + 255) / 256) * 256, c5 = ((t5 + 255) / 256) * 160;
-        const bool use5 = force_tm() == 5 || force_tm() == 160 || (force_tm() == 0 && c5 * 11 < c8 * 10);
-        const bool use32 = force_tm() == 32 || (force_tm() == 0 && t5 > 320 && a.K % N3_BK == 0);
-        const bool use4w = force_tm() == 4;   // 160x128, two workgroups per CU: measured equal to the 8-wave 160x256 tile, kept as an option
+        // pick the tile height by wave quantisation: cost ~ (rounds over 256 CUs) x (cost of one tile-round)
+        const int f = force_tm();
+        const long t5 = (long)ce_div_up(a.M, 160) * a.tiles_n;
+        int best = 8;
+        long best_cost = -1;
+        if (f >= 3 && f <= 8) {
+            best = f;
+        } else {
+            for (int tm = 8; tm >= 3; --tm) {
+                const long cost = nt256_cost((long)ce_div_up(a.M, 32 * tm) * a.tiles_n, tm);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = tm; }
+            }
+        }
+        const bool use32 = f == 32 || (f == 0 && a.K % N3_BK == 0 && nt32_cost(t5) < best_cost);
         if (use32) {
             a.tiles_m = ce_div_up(a.M, N3_BM);
             hipLaunchKernelGGL(gemm_nt32_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N3_LDS_BYTES, stream, a);
-        } else if (use4w) {
+        } else if (f == 104) {   // 160x128, two workgroups per CU: measured equal to the 8-wave 160x256 tile, kept as an option
             a.tiles_m = ce_div_up(a.M, 160);
             a.tiles_n = ce_div_up(a.N, 128);
             hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), N2H_LDS_BYTES, stream, a);
-        } else if (use5 && force_tm() == 160) {      // three-stage ring: measured 6 % slower than the two-stage loop (the
-                                                     // K loop is LDS-bandwidth bound, not DMA-latency bound); kept as an option
+        } else if (f == 160) {   // three-stage ring: measured 6 % slower than the two-stage loop (the K loop is
+                                 // LDS-bandwidth bound, not DMA-latency bound); kept as an option
             a.tiles_m = ce_div_up(a.M, 160);
             hipLaunchKernelGGL(gemm_nt160_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N4_LDS_BYTES, stream, a);
-        } else if (use5) {
-            a.tiles_m = ce_div_up(a.M, 160);
-            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 5, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
         } else {
-            a.tiles_m = ce_div_up(a.M, 256);
-            hipLaunchKernelGGL((gemm_nt256_kernel<EPI, 8, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
+            switch (best) {
+                case 3: launch_nt256<EPI, 3>(a, stream); break;
+                case 4: launch_nt256<EPI, 4>(a, stream); break;
+                case 5: launch_nt256<EPI, 5>(a, stream); break;
+                case 6: launch_nt256<EPI, 6>(a, stream); break;
+                case 7: launch_nt256<EPI, 7>(a, stream); break;
+                default: launch_nt256<EPI, 8>(a, stream); break;
+            }
         }
     } else {
         hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
@@ -1113,6 +1143,8 @@ int launch_nt(NTArgs a, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" void ce_gemm_nt_tune(int variant) { g_force_tm = variant; }
 
 extern "C" int ce_gemm_nt(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int epilogue,
                           const float* bias, const float* resid, long ldr, void* out, long ldo, void* out2,
