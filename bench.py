@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dense-text", action="store_true",
                     help="run the text tower on all 77 positions of every caption (default: live tokens SOT..EOT only; "
                          "the default run also reports this dense variant as config.dense_text)")
+    ap.add_argument("--no-dense-compare", action="store_true", help="skip the dense-text comparison run")
     ap.add_argument("--fresh-captions", action="store_true",
                     help="hand the model a NEW caption tensor every step (forces the per-batch length read-back)")
     ap.add_argument("--single-stream", action="store_true",
@@ -96,6 +97,23 @@ def cpu_baseline():
     dt = (time.time() - t0) / n
     return {"value": round(B / dt, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} full train steps of ViT-B/32 at batch {B} (BASELINE config 1), fp32, CPU oracle"}
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected
+    + WRITE_SIZE, tools/pmc_traffic.py; PMC needs its own runs, so bench.py cannot collect it live)."""
+    import glob
+    prefix = {"gemm_tn": "gemm_tn2_kernel"}.get(kernel_class)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic*.json")))
+    if not prefix or not files:
+        return None, None
+    try:
+        for row in json.load(open(files[-1])):
+            if row["kernel"].startswith(prefix):
+                return (row["fetch_corrected_x2_MB"] + row["WRITE_SIZE_MB_per_launch"]) * 1e6, os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
 
 
 def ms_per_step_tmp(dt, steps):
@@ -176,7 +194,7 @@ def main():
     lens = (txt.argmax(dim=-1) + 1).sum().item()
     live_frac = 1.0 if args.dense_text else lens / float(B * 77)
     dense = None
-    if not args.dense_text:      # the same step with every caption padded out to 77 rows, for comparison
+    if not args.dense_text and not args.no_dense_compare:      # the same step with every caption padded out to 77 rows, for comparison
         model.pack_text = False
         nd = max(5, args.steps // 2)
         for _ in range(2):
@@ -224,8 +242,11 @@ def main():
         mfma = top["kernel"].startswith("gemm") or top["kernel"].startswith("attn")
         ach = top["tflops"] if mfma else top["gbps"]
         peak = PEAK_BF16 / 1e12 if mfma else PEAK_HBM / 1e9
+        traffic, traffic_src = pmc_traffic(top["kernel"])
         roof = {"bound": "mfma" if mfma else "hbm", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
+                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(top["gbps"] * 1e9 * top["avg_us"] * 1e-6),
                 "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
                 # nominal = SURVEY 8(d)'s 44.10 GFLOP/pair (all 77 text positions); executed = FLOPs actually issued
                 # (text-tower GEMM work scales with the live-row fraction)

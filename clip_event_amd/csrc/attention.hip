@@ -69,19 +69,24 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16_t* __restrict_
     const int Tl = ((L + 31) >> 5) << 1;            // live 16-key tiles (even), block-uniform
     const bf16_t* base = qkv + row0 * ld + h * HD;
 
+    // one 16-query strip per wave (the launch uses ceil(Lmax/16) waves); its Q rows are requested before the K / V
+    // staging so that the two memory latencies overlap
+    const int li = lane & 15, g = lane >> 4;
+    const int nstrips = (L + 15) >> 4;
+    const int strip = wave;
+    const int i = strip * 16 + li;               // this lane's query
+    const int iq = min(i, L - 1);
+    bf16x8 qf[2];
+    if (strip < nstrips) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+    }
     stage_head(sK, base + D, ld, L, Tl * 16, tid, blockDim.x);
     stage_head(sV, base + 2 * D, ld, L, Tl * 16, tid, blockDim.x);
     __syncthreads();
 
-    const int li = lane & 15, g = lane >> 4;
-    const int nstrips = (L + 15) >> 4;
-    for (int strip = wave; strip < nstrips; strip += nw) {
-        const int i = strip * 16 + li;               // this lane's query
-        const int iq = min(i, L - 1);
-        bf16x8 qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+    if (strip < nstrips) {
         f32x4 s[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -177,37 +182,62 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     bf16_t* dbase = dqkv + row0 * lddq + h * HD;
 
     for (int i = tid; i < 192; i += blockDim.x) csum[i] = 0.f;   // the workgroup may have fewer than 192 threads
-    stage_head(sA, base + D, ld, L, Ll, tid, blockDim.x);        // K
-    stage_head(sB, base + 2 * D, ld, L, Ll, tid, blockDim.x);    // V
-    __syncthreads();
-
     const int li = lane & 15, g = lane >> 4;
-    // ---------------- phase 1: per 16-query strip ----------------
-    for (int strip = wave; strip < Tl; strip += nw) {
-        const int i = strip * 16 + li;
-        const bool iok = i < L;
-        const int iq = min(i, L - 1);
-        // delta_i = sum_c dO[i][c] O[i][c]; each of the 4 lanes of a query takes 16 columns
-        float dl = 0.f;
-        {
-            const u32x4* pd = reinterpret_cast<const u32x4*>(dob + (long)iq * lddo + g * 16);
-            const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)iq * ldo + g * 16);
+    // ---- every global read of the workgroup is issued up front (one exposed memory latency instead of three):
+    // the K, V, Q, dO head slices (<= 2 16-byte chunks per matrix per thread: blockDim = 64 T >= Lp*8/2) and this
+    // wave's own query strip (one strip per wave: the launch uses T waves) ----
+    u32x4 rK[2], rV[2], rQ[2], rD[2];
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                u32x4 a = pd[v], c = po[v];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dl += bf_lo(a[e]) * bf_lo(c[e]) + bf_hi(a[e]) * bf_hi(c[e]);
-            }
-            dl += __shfl_xor(dl, 16, 64);
-            dl += __shfl_xor(dl, 32, 64);
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + c * blockDim.x;
+        const int r = idx >> 3, ch = idx & 7;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        rK[c] = z; rV[c] = z; rQ[c] = z; rD[c] = z;
+        if (idx < Ll * 8 && r < L) {
+            rK[c] = *reinterpret_cast<const u32x4*>(base + D + (long)r * ld + ch * 8);
+            rV[c] = *reinterpret_cast<const u32x4*>(base + 2 * D + (long)r * ld + ch * 8);
+            rQ[c] = *reinterpret_cast<const u32x4*>(base + (long)r * ld + ch * 8);
+            rD[c] = *reinterpret_cast<const u32x4*>(dob + (long)r * lddo + ch * 8);
         }
-        const float lsei = lse[((long)b * H + h) * Lmax + iq];
-        bf16x8 qf[2], df[2];       // B operands: rows of Q and dO straight from global (only this wave needs them)
+    }
+    const int strip = wave;                       // phase 1: one 16-query strip per wave
+    const bool has_strip = strip < Tl;
+    const int i = strip * 16 + li;
+    const bool iok = has_strip && i < L;
+    const int iq = min(i, L - 1);
+    float dl = 0.f, lsei = 0.f;
+    bf16x8 qf[2], df[2];       // B operands: rows of Q and dO straight from global (only this wave needs them)
+    if (has_strip) {
+        // delta_i = sum_c dO[i][c] O[i][c]; each of the 4 lanes of a query takes 16 columns
+        const u32x4* pd = reinterpret_cast<const u32x4*>(dob + (long)iq * lddo + g * 16);
+        const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)iq * ldo + g * 16);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            u32x4 a = pd[v], c = po[v];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dl += bf_lo(a[e]) * bf_lo(c[e]) + bf_hi(a[e]) * bf_hi(c[e]);
+        }
+        lsei = lse[((long)b * H + h) * Lmax + iq];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
             df[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)iq * lddo + ks * 32 + g * 8);
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + c * blockDim.x;
+        if (idx < Ll * 8) {
+            *reinterpret_cast<u32x4*>(sA + (idx >> 3) * ROW + (idx & 7) * 16) = rK[c];
+            *reinterpret_cast<u32x4*>(sB + (idx >> 3) * ROW + (idx & 7) * 16) = rV[c];
+        }
+    }
+    __syncthreads();
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+
+    // ---------------- phase 1: this wave's 16-query strip ----------------
+    if (has_strip) {
         f32x4 p[T], ds[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -258,20 +288,26 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 *reinterpret_cast<u32x2*>(qrow + ct * 16) = pk;
             }
         }
-        if (bias_grad) {   // sum over the strip's 16 queries (lanes of a 16-lane group); padded queries are exact zeros
+        if (bias_grad) {   // sum over the strip's 16 queries (one DPP row); padded queries are exact zeros
+            float vals[16];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[ct][r];
-                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                    if (li == 0) atomicAdd(&csum[ct * 16 + 4 * g + r], v);
-                }
+                for (int r = 0; r < 4; ++r) vals[ct * 4 + r] = acc[ct][r];
+            const float tot = row16_colsum(vals, li);
+            const int k = row16_colsum_index(li);
+            atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tot);
         }
     }
     __syncthreads();                                             // K, V no longer needed; P / dS images complete
-    stage_head(sA, base, ld, L, Ll, tid, blockDim.x);            // Q
-    stage_head(sB, dob, lddo, L, Ll, tid, blockDim.x);           // dO
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + c * blockDim.x;
+        if (idx < Ll * 8) {
+            *reinterpret_cast<u32x4*>(sA + (idx >> 3) * ROW + (idx & 7) * 16) = rQ[c];   // Q
+            *reinterpret_cast<u32x4*>(sB + (idx >> 3) * ROW + (idx & 7) * 16) = rD[c];   // dO
+        }
+    }
     __syncthreads();
     // ---------------- phase 2: per 16-key tile ----------------
     const int nkt = (L + 15) >> 4;
@@ -314,19 +350,19 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 *reinterpret_cast<u32x2*>(vrow + ct * 16) = pv;
             }
         }
-        if (bias_grad) {
+        if (bias_grad) {   // rows j >= L of the tile are exact zeros (their P / dS columns are)
+            float vk[16], vv[16];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float vk = ak[ct][r], vv = av[ct][r];
-                    vk += __shfl_xor(vk, 1, 64); vk += __shfl_xor(vk, 2, 64); vk += __shfl_xor(vk, 4, 64); vk += __shfl_xor(vk, 8, 64);
-                    vv += __shfl_xor(vv, 1, 64); vv += __shfl_xor(vv, 2, 64); vv += __shfl_xor(vv, 4, 64); vv += __shfl_xor(vv, 8, 64);
-                    if (li == 0) {
-                        atomicAdd(&csum[64 + ct * 16 + 4 * g + r], vk);
-                        atomicAdd(&csum[128 + ct * 16 + 4 * g + r], vv);
-                    }
+                    vk[ct * 4 + r] = ak[ct][r];
+                    vv[ct * 4 + r] = av[ct][r];
                 }
+            const float tk = row16_colsum(vk, li), tv = row16_colsum(vv, li);
+            const int k = row16_colsum_index(li);
+            atomicAdd(&csum[64 + (k >> 2) * 16 + 4 * g + (k & 3)], tk);
+            atomicAdd(&csum[128 + (k >> 2) * 16 + 4 * g + (k & 3)], tv);
         }
     }
     if (bias_grad) {

@@ -62,6 +62,30 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- DPP row (16-lane) reductions: VALU only, no LDS crossbar (a __shfl_xor is a ds_bpermute_b32 + wait) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {   // every lane active (EXEC all ones) at the call sites
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// Column sums of a 16 x 16 register block held one row per lane of a 16-lane DPP row (v[k] = element k of lane
+// li's row): transpose-reduce butterfly over the pairings row_mirror, row_half_mirror, quad xor 1, quad xor 2 --
+// each stage halves the values a lane keeps and adds the partner's copy (15 DPP adds instead of 64).  Lane li
+// returns sum_lanes v[k] for k = row16_colsum_index(li).
+__device__ __forceinline__ int row16_colsum_index(int li) {
+    return (li & 8) | (li & 4) | ((li & 1) << 1) | ((li & 2) >> 1);
+}
+__device__ __forceinline__ float row16_colsum(const float (&v)[16], int li) {
+    const bool s1 = li & 8, s2 = li & 4, s3 = li & 1, s4 = li & 2;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (s1 ? v[k + 8] : v[k]) + dpp_mov<0x140>(s1 ? v[k] : v[k + 8]);   // row_mirror
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = (s2 ? a[k + 4] : a[k]) + dpp_mov<0x141>(s2 ? a[k] : a[k + 4]);   // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < 2; ++k) c[k] = (s3 ? b[k + 2] : b[k]) + dpp_mov<0x0B1>(s3 ? b[k] : b[k + 2]);   // quad_perm [1,0,3,2]
+    return (s4 ? c[1] : c[0]) + dpp_mov<0x04E>(s4 ? c[0] : c[1]);                                       // quad_perm [2,3,0,1]
+}
+
 // ---- buffer resources (bounds-checked: out-of-range loads return 0, stores are dropped) ----
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
