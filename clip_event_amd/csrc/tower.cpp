@@ -195,9 +195,18 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, int rows, con
 
 extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
                                  void* workspace, float* dx, const int* sel_rows, const float* dx_sel, void* stream) {
+    return ce_tower_backward_range(d, batch, rows, cu_seqlens, x0, workspace, dx, sel_rows, dx_sel,
+                                   d ? d->layers - 1 : 0, 0, stream);
+}
+
+extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens,
+                                       const float* x0, void* workspace, float* dx, const int* sel_rows,
+                                       const float* dx_sel, int layer_hi, int layer_lo, void* stream) {
     TRY(check_desc(d, batch));
     TRY(check_rows(d, batch, rows, cu_seqlens));
     CE_CHECK_ARG(x0 && workspace && dx, "ce_tower_backward: null buffer");
+    CE_CHECK_ARG(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi < d->layers, "ce_tower_backward_range: layers %d..%d outside 0..%d",
+                 layer_hi, layer_lo, d->layers - 1);
     Layout L;
     carve(d, batch, rows, workspace, L);
     const int M = rows, w = d->width;
@@ -218,8 +227,10 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, int rows, co
     auto wait_done = [&](int l) {        // main stream: do not overwrite set (l&1) before wgrad(l) has read it
         if (sc && l >= 0 && l <= last) hipStreamWaitEvent(ms, sc->done[l], 0);
     };
-    int top = last;
-    if (sel_rows) {
+    int top = layer_hi;
+    if (layer_hi < last) {
+        // continuation of an earlier call: dx and the bf16 copy in set (layer_hi & 1) were left by block layer_hi+1
+    } else if (sel_rows) {
         // ---- pruned last block (see ce_tower_forward): compact rows through the MLP and the out-projection ----
         CE_CHECK_ARG(dx_sel, "ce_tower_backward: pruned mode needs dx_sel");
         const int l = top, Bn = batch, q = l & 1;
@@ -267,7 +278,7 @@ extern "C" int ce_tower_backward(const ce_tower_desc* d, int batch, int rows, co
     } else {
         TRY(ce_cast_bf16(dx, L.dxb[top & 1], (long)M * w, stream));
     }
-    for (int l = top; l >= 0; --l) {
+    for (int l = top; l >= layer_lo; --l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
         const int q = l & 1;

@@ -9,8 +9,8 @@ the *global*-batch loss, so this module provides
   the W-rank gradient equal to the single-process gradient on the concatenated batch once the
   parameter gradients are averaged (SURVEY.md H3);
 * ``global_labels``: the label/index layout of dataset_voa.py:615-663 offset by ``rank*B``;
-* ``GradSync``: mean all-reduce of the model's flat gradient buffer, one bucket per tower,
-  launched as soon as that tower's backward has been enqueued so it overlaps the other tower;
+* ``GradSync``: mean all-reduce of the model's flat gradient buffer in a few pieces per tower, each
+  launched as soon as the backward has enqueued the blocks it covers, so it overlaps the rest;
 * ``reduce_dict``: utils.py:136-160 (logging only).
 
 Everything here is device-agnostic (the CPU tests run it on gloo with world_size 2).
@@ -102,25 +102,36 @@ def reduce_dict(input_dict: Dict[str, torch.Tensor], average: bool = True) -> Di
 
 
 class GradSync:
-    """Mean all-reduce of the flat gradient buffer, bucketed per tower.
+    """Mean all-reduce of the flat gradient buffer, bucketed per tower and, inside a tower, per group of
+    residual blocks.
 
-    ``model.grad_sync`` is called by each tower's backward right after its last launch was
-    enqueued; the bucket's all-reduce is issued asynchronously (RCCL runs it on its own stream)
-    and overlaps the other tower's backward.  ``finish()`` reduces the small head bucket and
-    waits for everything before the optimiser runs."""
+    ``model.grad_sync`` is called by each tower's backward: after every layer range (``upto_layer``: the blocks
+    down to that one are final; their gradients are a contiguous prefix of the tower's range, model._prepare) and
+    once more when the whole tower, embeddings included, has been enqueued.  Each piece's all-reduce is issued
+    asynchronously (RCCL runs it on its own stream, ordered after the launches enqueued so far) and overlaps the
+    rest of the backward.  ``finish()`` reduces what is left (logit_scale) and waits for everything before the
+    optimiser runs.  xGMI is point-to-point, so a ring all-reduce of the 600 MB buffer costs milliseconds: only
+    the last piece (lowest blocks + input embeddings of the tower that finishes last) stays exposed."""
 
-    def __init__(self, model):
+    def __init__(self, model, pieces_per_tower: int = 3):
         self.model = model
+        self.pieces = max(1, int(pieces_per_tower))
         self.pending = []
         self.done = set()
-        model.grad_sync = self._on_tower
+        self.progress = {}
+        model.grad_sync = self            # callable: (model, tower, upto_layer=None); also queried for layer_cuts
 
-    def _reduce(self, name: str, async_op: bool):
-        m = self.model
-        a, b = m._ranges[name]
+    def layer_cuts(self, tower: str, layers: int):
+        """Blocks at which a tower's backward pauses to hand over gradients: ``pieces`` roughly equal groups."""
+        if world_size() < 2 or self.pieces < 2 or tower in self.done:
+            return []
+        cuts = sorted({(layers * k) // self.pieces for k in range(1, self.pieces)}, reverse=True)
+        return [c for c in cuts if 0 < c < layers]
+
+    def _reduce_range(self, a: int, b: int, async_op: bool):
         if b <= a:
             return
-        buf = m._flat_grad[a:b]
+        buf = self.model._flat_grad[a:b]
         W = world_size()
         if dist.get_backend() == "gloo":
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
@@ -130,12 +141,23 @@ class GradSync:
             if async_op:
                 self.pending.append(h)
 
-    def _on_tower(self, model, name: str):
+    def _reduce(self, name: str, async_op: bool):
+        a, b = self.model._ranges[name]
+        self._reduce_range(a, b, async_op)
+
+    def _on_tower(self, model, name: str, upto_layer: Optional[int] = None):
         if world_size() < 2 or name in self.done:
             return
-        # a tower that runs several passes per step (sim_entity, region branch) is reduced at finish()
-        self.done.add(name)
-        self._reduce(name, async_op=True)
+        # a tower that runs several passes per step (sim_entity, region branch) is reduced again at finish()
+        a, b = model._ranges[name]
+        start = self.progress.get(name, a)
+        end = b if upto_layer is None else model._layer_end[name][upto_layer]
+        self._reduce_range(start, end, async_op=True)
+        self.progress[name] = end
+        if upto_layer is None:
+            self.done.add(name)
+
+    __call__ = _on_tower
 
     def finish(self, passes_per_tower: int = 1):
         if world_size() < 2:
@@ -149,9 +171,11 @@ class GradSync:
         else:
             for name in ("visual", "text"):
                 if name not in self.done:
-                    self._reduce(name, async_op=False)
+                    a, b = self.model._ranges[name]
+                    self._reduce_range(self.progress.get(name, a), b, async_op=False)
         self._reduce("head", async_op=False)
         for h in self.pending:
             h.wait()
         self.pending = []
         self.done = set()
+        self.progress = {}

@@ -43,6 +43,25 @@ def _publish_to_main(ctx):
             ms.wait_stream(cur)
 
 
+def _tower_backward(model, desc, tower: str, batch: int, rows: int, cu, x0, lease, dx, sel, dx_sel):
+    """Tower backward, cut into layer ranges when a data-parallel gradient exchange is attached: after every
+    range the gradients of the blocks done so far are handed to ``model.grad_sync`` (they form a contiguous
+    prefix of the tower's range in the flat gradient buffer, model._prepare), so their all-reduce overlaps the
+    remaining blocks."""
+    cl, s = lib(), stream()
+    layers = desc.layers
+    cuts = model.grad_sync.layer_cuts(tower, layers) if (model.grad_sync is not None and
+                                                           hasattr(model.grad_sync, "layer_cuts")) else []
+    hi = layers - 1
+    for lo in list(cuts) + [0]:
+        check(cl.ce_tower_backward_range(ctypes.byref(desc), c_int(batch), c_int(rows), ptr(cu), ptr(x0), ptr(lease.buf),
+                                         ptr(dx), ptr(sel), ptr(dx_sel), c_int(hi), c_int(lo), s),
+              f"ce_tower_backward_range({tower})")
+        if lo > 0:
+            model.grad_sync(model, tower, upto_layer=lo)
+        hi = lo - 1
+
+
 class TextPacking:
     """Row layout of one caption batch in the text tower.  ``cu is None``: dense, every caption owns
     ``context_length`` rows.  Otherwise only the live tokens (SOT .. EOT) are rows: ``cu`` int32 [n+1] prefix sums,
@@ -179,13 +198,10 @@ class EncodeImageFn(torch.autograd.Function):
                                   c_int(D), s), "ce_layernorm_bwd(ln_post)")
         if rows is None:
             dx = dxn
-            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), c_int(M), None, ptr(x0), ptr(lease.buf),
-                                       ptr(dx), None, None, s),
-                  "ce_tower_backward(vision)")
+            _tower_backward(model, model._vdesc, "visual", B, M, None, x0, lease, dx, None, None)
         else:
             dx = _empty((M, D), torch.float32, dev)
-            check(cl.ce_tower_backward(ctypes.byref(model._vdesc), c_int(B), c_int(M), None, ptr(x0), ptr(lease.buf),
-                                       ptr(dx), ptr(rows), ptr(dxn), s), "ce_tower_backward(vision)")
+            _tower_backward(model, model._vdesc, "visual", B, M, None, x0, lease, dx, rows, dxn)
         lease.release()
         # ln_pre: x0 = LN(xpre)
         dxpre = _empty((M, D), torch.float32, dev)
@@ -279,8 +295,7 @@ class EncodeTextFn(torch.autograd.Function):
                                   ptr(G("ln_final.weight")), ptr(G("ln_final.bias")), None, c_int(n), c_int(D), s),
               "ce_layernorm_bwd(ln_final)")
         dx = _empty((M, D), torch.float32, dev)
-        check(cl.ce_tower_backward(ctypes.byref(model._tdesc), c_int(n), c_int(M), ptr(pk.cu), ptr(x0), ptr(lease.buf),
-                                   ptr(dx), ptr(rows), ptr(dxn), s), "ce_tower_backward(text)")
+        _tower_backward(model, model._tdesc, "text", n, M, pk.cu, x0, lease, dx, rows, dxn)
         lease.release()
         if pk.cu is None:
             check(cl.ce_batch_reduce(ptr(dx), ptr(G("positional_embedding")), c_int(n), c_long(T * D), c_long(T * D),

@@ -248,21 +248,54 @@ class CLIP(nn.Module):
         lib()
         named = list(self.named_parameters())
         offsets, off = {}, 0
-        # contiguous ranges per tower so that each tower's gradients form one communication bucket
-        order = ([n for n, _ in named if not n.startswith("visual.") and not n.startswith("transformer.")]
-                 + [n for n, _ in named if n.startswith("visual.")]
-                 + [n for n, _ in named if n.startswith("transformer.")])
         pmap = dict(named)
-        ranges = {}
-        for group, pred in (("head", lambda n: not n.startswith(("visual.", "transformer."))),
-                            ("visual", lambda n: n.startswith("visual.")),
-                            ("text", lambda n: n.startswith("transformer."))):
+        # Contiguous range per tower, and inside a tower the parameters in the order their gradients become final
+        # during the backward (output side first, residual blocks top-down, input embeddings last): the gradients
+        # of "everything above block l" are then one contiguous prefix of the tower's range, which lets the
+        # data-parallel all-reduce start on it while the lower blocks are still running (distributed.GradSync).
+        text_side = ("token_embedding.", "positional_embedding", "ln_final.", "text_projection")
+
+        def block_of(n):
+            parts = n.split(".")
+            return int(parts[parts.index("resblocks") + 1]) if "resblocks" in parts else None
+
+        def tower_order(names, first, last_):
+            head = [n for n in names if block_of(n) is None and any(n.startswith(f) for f in first)]
+            tail = [n for n in names if block_of(n) is None and any(n.startswith(f) for f in last_)]
+            rest = [n for n in names if block_of(n) is None and n not in head and n not in tail]
+            if rest:
+                raise RuntimeError(f"unplaced parameters {rest}")
+            blocks = sorted({block_of(n) for n in names if block_of(n) is not None}, reverse=True)
+            return head, [[n for n in names if block_of(n) == b] for b in blocks], blocks, tail
+
+        groups = {
+            "head": ([n for n, _ in named if not n.startswith(("visual.", "transformer.") + text_side)], [], [], []),
+            "visual": tower_order([n for n, _ in named if n.startswith("visual.")],
+                                  ("visual.ln_post.", "visual.proj"),
+                                  ("visual.ln_pre.", "visual.conv1.", "visual.positional_embedding", "visual.class_embedding")),
+            "text": tower_order([n for n, _ in named if n.startswith(("transformer.",) + text_side)],
+                                ("ln_final.", "text_projection"), ("positional_embedding", "token_embedding.")),
+        }
+        ranges, layer_end = {}, {}
+        for group in ("head", "visual", "text"):
+            head, per_block, blocks, tail = groups[group]
             start = off
-            for n in order:
-                if pred(n):
+            layer_end[group] = {}
+            for n in head:
+                offsets[n] = off
+                off += (pmap[n].numel() + 63) // 64 * 64
+            for b, names_b in zip(blocks, per_block):
+                for n in names_b:
                     offsets[n] = off
                     off += (pmap[n].numel() + 63) // 64 * 64
+                layer_end[group][b] = off          # gradients of blocks >= b (and the output side) end here
+            for n in tail:
+                offsets[n] = off
+                off += (pmap[n].numel() + 63) // 64 * 64
             ranges[group] = (start, off)
+        if len(offsets) != len(named):
+            raise RuntimeError("flat layout lost a parameter")
+        self._layer_end = layer_end
         flat = torch.zeros(off, dtype=torch.float32, device=dev)
         flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
         with torch.no_grad():

@@ -212,6 +212,13 @@ int ce_tower_forward(const ce_tower_desc* d, int batch, int rows, const int* cu_
  * output only.  Parameter gradients are accumulated into the g_* buffers. */
 int ce_tower_backward(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
                       void* workspace, float* dx, const int* sel_rows, const float* dx_sel, void* stream);
+/* the same backward for blocks layer_hi .. layer_lo only (both inclusive, top-down); successive calls covering
+ * layers-1 .. 0 with the same buffers equal one ce_tower_backward.  After the call that ends at block l the
+ * gradients of every block >= l are final, so a data-parallel caller can start reducing them
+ * (clip_event_amd/distributed.py) while the lower blocks still run. */
+int ce_tower_backward_range(const ce_tower_desc* d, int batch, int rows, const int* cu_seqlens, const float* x0,
+                            void* workspace, float* dx, const int* sel_rows, const float* dx_sel, int layer_hi,
+                            int layer_lo, void* stream);
 
 /* ---- optimal-transport alignment + region pooling (ot.hip) ---- */
 /* dist[b] = trace(C_b T_b): cosine cost between txt[b] (M rows) and img[b] (N rows), IPOT plan
