@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // dst[c][r] = src[r][c] for a table of bf16 matrices, one launch: the transposed operand copies of every
 // weight (input-gradient GEMMs read W^T) are rebuilt from the bf16 mirror the Adam kernel wrote.
 __global__ __launch_bounds__(256) void multi_transpose_kernel(const ce_transpose_job* __restrict__ jobs, int njobs) {
+    // 64 x 64 tile through LDS; global accesses are 16 bytes per lane on both sides when rows/cols are multiples
+    // of 8 (every weight here), 2 bytes per lane otherwise.  Row stride 66 elements = 33 dwords: the 8 rows a lane
+    // gathers for one 16-byte transposed store sit in 8 different banks.
     __shared__ bf16_t tile[64][66];
     int j = 0;
     const int b = blockIdx.x;
@@ -87,6 +90,35 @@ __global__ __launch_bounds__(256) void multi_transpose_kernel(const ce_transpose
     const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
     const bf16_t* src = reinterpret_cast<const bf16_t*>(job.src);
     bf16_t* dst = reinterpret_cast<bf16_t*>(job.dst);
+    const bool wide = (job.rows % 8 == 0) && (job.cols % 8 == 0) &&
+                      ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) % 16 == 0);
+    if (wide) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = threadIdx.x + k * 256;                 // 64 rows x 8 chunks
+            const int r = idx >> 3, ch = idx & 7;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r0 + r < job.rows && c0 + ch * 8 < job.cols)
+                v = *reinterpret_cast<const u32x4*>(src + (long)(r0 + r) * job.cols + c0 + ch * 8);
+            uint32_t* trow = reinterpret_cast<uint32_t*>(&tile[r][ch * 8]);
+            trow[0] = v[0]; trow[1] = v[1]; trow[2] = v[2]; trow[3] = v[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = threadIdx.x + k * 256;                 // 64 output rows (source columns) x 8 chunks
+            const int c = idx >> 3, ch = idx & 7;
+            if (c0 + c < job.cols && r0 + ch * 8 < job.rows) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w[e] = (uint32_t)tile[ch * 8 + 2 * e][c] | ((uint32_t)tile[ch * 8 + 2 * e + 1][c] << 16);
+                u32x4 v = {w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<u32x4*>(dst + (long)(c0 + c) * job.rows + r0 + ch * 8) = v;
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;        // 64 x 4
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {

@@ -240,3 +240,24 @@ def test_gemm_nt_gelugrad_fused_colsum(M, N, K):
     ref = (a.float() @ b.float().t()) * (s * (1 + 1.702 * x * (1 - s)))
     assert _report("gelugrad out", out.float().cpu(), ref)[1] < 3e-3
     assert _report("gelugrad colsum", cs.cpu(), ref.sum(0))[1] < 2e-3
+
+
+def test_multi_transpose_table():
+    """One launch transposes a table of bf16 matrices (W^T operand copies): 16-byte path and the ragged 2-byte path."""
+    from ctypes import c_int
+    from clip_event_amd._lib import TransposeJob, check, lib, ptr, stream
+    rng = np.random.default_rng(42)
+    shapes = [(768, 2304), (512, 512), (72, 64), (100, 36), (50, 7), (3072, 768), (8, 8)]
+    srcs = [torch.from_numpy(rng.standard_normal(sh).astype(np.float32)).to(torch.bfloat16).to(DEV) for sh in shapes]
+    dsts = [torch.full((sh[1], sh[0]), float("nan"), dtype=torch.bfloat16, device=DEV) for sh in shapes]
+    jobs = (TransposeJob * len(shapes))()
+    tiles = 0
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        jobs[i].src, jobs[i].dst = a.data_ptr(), b.data_ptr()
+        jobs[i].rows, jobs[i].cols, jobs[i].tile_start = a.shape[0], a.shape[1], tiles
+        tiles += ((a.shape[0] + 63) // 64) * ((a.shape[1] + 63) // 64)
+    tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
+    check(lib().ce_multi_transpose_bf16(ptr(tab), c_int(len(shapes)), c_int(tiles), stream()), "ce_multi_transpose_bf16")
+    torch.cuda.synchronize()
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b.view(torch.int16).cpu(), a.t().contiguous().view(torch.int16).cpu()), tuple(a.shape)
