@@ -502,6 +502,33 @@ def adam_step(p, grads, state, lr: float, weight_decay: float = 0.0,
     return out
 
 
+def warmup_factor_at(method: str, it: int, warmup_iters: int, warmup_factor: float) -> float:
+    """``_get_warmup_factor_at_iter`` (utils.py:393-416)."""
+    if it >= warmup_iters:
+        return 1.0
+    if method == "constant":
+        return warmup_factor
+    if method == "linear":
+        alpha = it / warmup_iters
+        return warmup_factor * (1 - alpha) + alpha
+    raise ValueError("Unknown warmup method: {}".format(method))
+
+
+def lr_warmup_cosine(base_lr: float, it: int, max_iters: int, warmup_factor: float = 0.001, warmup_epochs: int = 5,
+                     warmup_method: str = "linear") -> float:
+    """``WarmupCosineLR.get_lr`` (utils.py:368-384) at ``last_epoch = it``."""
+    w = warmup_factor_at(warmup_method, it, warmup_epochs, warmup_factor)
+    return base_lr * w * 0.5 * (1.0 + math.cos(math.pi * it / max_iters))
+
+
+def lr_warmup_multistep(base_lr: float, it: int, milestones, gamma: float = 0.1, warmup_factor: float = 0.001,
+                        warmup_epochs: int = 5, warmup_method: str = "linear") -> float:
+    """``WarmupMultiStepLR.get_lr`` (utils.py:334-343) at ``last_epoch = it``."""
+    w = warmup_factor_at(warmup_method, it, warmup_epochs, warmup_factor)
+    passed = sum(1 for m in milestones if m <= it)          # bisect_right(milestones, it)
+    return base_lr * w * gamma ** passed
+
+
 def train_step(p, cfg, state, image, text, labels_per_image, labels_per_text, index_pos,
                lr=1e-6, weight_decay=0.0, overbatch=True, bf16=False):
     """One iteration of ``train_one_epoch`` (engine.py:48-95) for the InfoNCE-only

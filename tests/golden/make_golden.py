@@ -47,6 +47,10 @@ _tv.transforms = _tvt
 sys.modules["torchvision"] = _tv
 sys.modules["torchvision.transforms"] = _tvt
 
+_mpi = types.ModuleType("mpi4py")       # utils.py imports utils_MPIAdapter -> mpi4py (absent); never called here
+_mpi.MPI = types.SimpleNamespace()
+sys.modules["mpi4py"] = _mpi
+
 import model_clip as ref_model          # noqa: E402  (the reference)
 import model_ot as ref_ot               # noqa: E402
 import utils_image as ref_img           # noqa: E402
@@ -302,10 +306,38 @@ def g_entity():
     return {"loss_ot": float(ld["loss_ot"]), "grads": grads_of(m)}
 
 
+def g_sched():
+    """Learning-rate schedules of utils.py:310-416 driven exactly as engine.py:97 does (one ``step()`` per
+    iteration after ``optimizer.step()``): the lr in force at iterations 0..N-1."""
+    import utils as ref_utils
+
+    def run(make, n):
+        w = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([w], lr=3e-4)
+        sch = make(opt)
+        lrs = []
+        for _ in range(n):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return lrs
+
+    return {
+        "base_lr": 3e-4,
+        "cosine": {"max_iters": 20, "warmup_epochs": 5, "n": 24,
+                   "lr": run(lambda o: ref_utils.WarmupCosineLR(o, 20, warmup_epochs=5), 24)},
+        "cosine_const": {"max_iters": 12, "warmup_epochs": 3, "warmup_factor": 0.1, "n": 12,
+                         "lr": run(lambda o: ref_utils.WarmupCosineLR(o, 12, warmup_factor=0.1, warmup_epochs=3,
+                                                                      warmup_method="constant"), 12)},
+        "multistep": {"milestones": [4, 9], "gamma": 0.1, "warmup_epochs": 3, "n": 14,
+                      "lr": run(lambda o: ref_utils.WarmupMultiStepLR(o, [4, 9], gamma=0.1, warmup_epochs=3), 14)},
+    }
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = {"tiny": g_tiny, "tiny_step": g_tiny_step, "vitb32": g_vitb32, "tokenizer": g_tokenizer,
-            "ot": g_ot, "region": g_region, "entity": g_entity}
+            "ot": g_ot, "region": g_region, "entity": g_entity, "sched": g_sched}
     path = os.path.join(HERE, "golden.json")
     if os.path.exists(path):
         out = json.load(open(path))

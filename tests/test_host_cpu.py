@@ -2,6 +2,8 @@
 when the HIP path cannot run."""
 import ctypes
 import os
+
+import numpy as np
 import re
 
 import pytest
@@ -82,3 +84,48 @@ def test_patch_from_norm_bbox_integer_contract():
     assert patch_from_norm_bbox((0.1, 0.1, 0.6, 0.7), 7) == (0, 0, 5, 5)       # SURVEY.md R2 [probed]
     for case in golden_json()["region"]["bbox7"]:
         assert list(patch_from_norm_bbox(tuple(case["bbox"]), 7)) == case["idx"]
+
+
+def test_lr_schedulers_match_reference_sequence():
+    """Product schedulers (host arithmetic, optim.py) driven as engine.py:97 does, against the reference's lr
+    sequences and the oracle."""
+    import torch
+    from oracle import clip_oracle as O
+    from clip_event_amd.optim import WarmupCosineLR, WarmupMultiStepLR, build_lr_scheduler
+    from tests.util import golden_json
+    G = golden_json()["sched"]
+
+    def run(make, n):
+        w = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([w], lr=G["base_lr"])
+        sch = make(opt)
+        out = []
+        for _ in range(n):
+            out.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return out
+
+    c = G["cosine"]
+    got = run(lambda o: WarmupCosineLR(o, c["max_iters"], warmup_epochs=c["warmup_epochs"]), c["n"])
+    np.testing.assert_allclose(got, c["lr"], rtol=1e-12)
+    np.testing.assert_allclose(got, [O.lr_warmup_cosine(G["base_lr"], i, c["max_iters"], warmup_epochs=c["warmup_epochs"])
+                                     for i in range(c["n"])], rtol=1e-12)
+    c = G["cosine_const"]
+    got = run(lambda o: WarmupCosineLR(o, c["max_iters"], warmup_factor=c["warmup_factor"], warmup_epochs=c["warmup_epochs"],
+                                       warmup_method="constant"), c["n"])
+    np.testing.assert_allclose(got, c["lr"], rtol=1e-12)
+    c = G["multistep"]
+    got = run(lambda o: WarmupMultiStepLR(o, c["milestones"], gamma=c["gamma"], warmup_epochs=c["warmup_epochs"]), c["n"])
+    np.testing.assert_allclose(got, c["lr"], rtol=1e-12)
+    # build_lr_scheduler (engine.py:154-176): kinds and the error text
+    w = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([w], lr=1e-3)
+    cfg = {"lr_scheduler": "warmup", "max_epoch": 10, "warmup_epoch": 2, "lr_steps": [3], "lr_gamma": 0.1}
+    assert isinstance(build_lr_scheduler(cfg, opt, 0), WarmupCosineLR)
+    assert build_lr_scheduler(dict(cfg, lr_scheduler="none"), opt, 0) is None
+    assert isinstance(build_lr_scheduler(dict(cfg, lr_scheduler="multisteplr"), opt, 0), torch.optim.lr_scheduler.MultiStepLR)
+    with pytest.raises(RuntimeError, match="Invalid lr scheduler"):
+        build_lr_scheduler(dict(cfg, lr_scheduler="bogus"), opt, 0)
+    with pytest.raises(ValueError, match="increasing"):
+        WarmupMultiStepLR(opt, [5, 2])

@@ -207,6 +207,63 @@ def test_train_step_fused_adam():
     assert worst > 0.9
 
 
+def test_fused_adam_is_a_torch_optimizer():
+    """FusedAdam under the reference's driver pattern (engine.py:87-97: zero_grad, backward, step, scheduler.step):
+    a stock LR scheduler drives it; its state_dict loads into torch.optim.Adam (and back) and both then take the
+    same next step from the same gradients (fp32 Adam arithmetic: 1e-6)."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    from clip_event_amd.optim import FusedAdam, WarmupCosineLR
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    m, sd = _mk(cfg, 21)
+    img = S.synthetic_images(4, cfg.image_resolution, seed=1).to(DEV)
+    txt = S.synthetic_tokens(4, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
+    yi, yt, ip = (t.to(DEV) for t in O.build_labels(4, 1, 0, True))
+    crit = CriterionContrastive("ce")
+    opt = FusedAdam(m, lr=1e-3, weight_decay=0.01, max_norm=None)
+    sch = WarmupCosineLR(opt, max_iters=10, warmup_epochs=3)
+    lrs = []
+
+    def backward():
+        ld = crit(*m(img, txt), yi, yt, index_pos=ip)
+        opt.zero_grad()
+        sum(ld.values()).backward()
+
+    for _ in range(3):
+        backward()
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    np.testing.assert_allclose(lrs, [O.lr_warmup_cosine(1e-3, i, 10, warmup_epochs=3) for i in range(3)], rtol=1e-12)
+    state = opt.state_dict()
+    assert set(state) == {"state", "param_groups"} and len(state["state"]) == len(list(m.parameters()))
+    assert all(int(st["step"]) == 3 for st in state["state"].values())
+    # the same state in torch's own Adam, over detached copies of the parameters, fed the same gradients
+    backward()
+    torch.cuda.synchronize()
+    twins = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+    for t, p in zip(twins, m.parameters()):
+        t.grad = p.grad.detach().clone()
+    ref = torch.optim.Adam(twins, lr=1e-3, weight_decay=0.01)
+    ref.load_state_dict(state)                      # also carries the scheduler-set lr
+    ref.step()
+    opt.step()
+    torch.cuda.synchronize()
+    worst = max(_rel(p.detach() - t0, t.detach() - t0) for p, t, t0 in
+                ((p, t, sd[n].to(DEV)) for (n, p), t in zip(m.named_parameters(), twins)))
+    print("FusedAdam vs torch.optim.Adam after state hand-over, worst rel-l2 of the accumulated delta:", worst)
+    assert worst < 1e-4
+    # and back: torch's state into a fresh FusedAdam
+    m2, _ = _mk(cfg, 21)
+    opt2 = FusedAdam(m2, lr=5e-4, max_norm=None)
+    opt2.load_state_dict(ref.state_dict())
+    assert opt2.step_count == 4 and abs(opt2.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-15
+    s2 = opt2.state_dict()
+    for i, st in ref.state_dict()["state"].items():
+        assert torch.equal(s2["state"][i]["exp_avg"].cpu(), st["exp_avg"].cpu())
+
+
 def test_ot_alignment_against_reference_golden():
     """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
     recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""

@@ -194,3 +194,18 @@ def test_label_layout_hand_derived():
     assert yi.tolist() == [0, 0, 0, 0]
     yi, yt, ip = O.build_labels(8, 1, 0, True)          # caption-only: all three = arange(8)
     assert yi.tolist() == yt.tolist() == ip.tolist() == list(range(8))
+
+
+def test_lr_schedules_against_reference_golden():
+    """utils.py:310-416 schedules: oracle restatement vs the lr sequence the reference's schedulers produced."""
+    G = golden_json()["sched"]
+    b = G["base_lr"]
+    c = G["cosine"]
+    got = [O.lr_warmup_cosine(b, i, c["max_iters"], warmup_epochs=c["warmup_epochs"]) for i in range(c["n"])]
+    np.testing.assert_allclose(got, c["lr"], rtol=1e-12, atol=0)
+    c = G["cosine_const"]
+    got = [O.lr_warmup_cosine(b, i, c["max_iters"], c["warmup_factor"], c["warmup_epochs"], "constant") for i in range(c["n"])]
+    np.testing.assert_allclose(got, c["lr"], rtol=1e-12, atol=0)
+    c = G["multistep"]
+    got = [O.lr_warmup_multistep(b, i, c["milestones"], c["gamma"], warmup_epochs=c["warmup_epochs"]) for i in range(c["n"])]
+    np.testing.assert_allclose(got, c["lr"], rtol=1e-12, atol=0)
