@@ -129,3 +129,34 @@ def test_lr_schedulers_match_reference_sequence():
         build_lr_scheduler(dict(cfg, lr_scheduler="bogus"), opt, 0)
     with pytest.raises(ValueError, match="increasing"):
         WarmupMultiStepLR(opt, [5, 2])
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """engine.py:202-218 / train.py:101-124: same five keys, same state-dict keys; fp16 weights (OpenAI release
+    format) widen to the fp32 masters; bare state dicts load too.  Read back with weights_only=True."""
+    import torch
+    from clip_event_amd import checkpoint as C
+    from clip_event_amd.model import build_model
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    sd = O.init_params(cfg, 4)
+    m = build_model({k: v.clone() for k, v in sd.items()})
+    path = C.save_model_on_master(m, str(tmp_path), "clipevent", 3, 0.25, optimizer=None)
+    assert path is not None and path.endswith("clipevent_3.pth")
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    assert tuple(blob.keys()) == C.CKPT_KEYS and blob["epoch"] == 3 and blob["model"] == "clipevent" and blob["perf"] == 0.25
+    assert list(blob["state_dict"].keys()) == list(sd.keys())
+    m2, opt_state, epoch, perf = C.load_checkpoint(path)
+    assert (opt_state, epoch, perf) == (None, 3, 0.25)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # bare fp16 state dict with the JIT archive's three extra keys
+    half = {k: (v.half() if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    half.update(input_resolution=torch.tensor(64), context_length=torch.tensor(20), vocab_size=torch.tensor(512))
+    bare = str(tmp_path / "bare.pt")
+    torch.save(half, bare)
+    m3, opt_state, epoch, perf = C.load_checkpoint(bare)
+    assert (opt_state, epoch, perf) == (None, 0, 0.0)
+    for k, v in m3.state_dict().items():
+        assert v.dtype == torch.float32 and torch.equal(v, sd[k].half().float()), k
+    with pytest.raises(FileNotFoundError, match="cannot find checkpoint"):
+        C.load_checkpoint(str(tmp_path / "missing.pth"))
