@@ -264,6 +264,27 @@ def test_fused_adam_is_a_torch_optimizer():
         assert torch.equal(s2["state"][i]["exp_avg"].cpu(), st["exp_avg"].cpu())
 
 
+def test_zero_shot_scoring_matches_oracle():
+    """preprocess_description_contrastive.py:127-132 on the HIP forward: 3 images against 7 candidate texts."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.inference import zero_shot
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    m, sd = _mk(cfg, 9)
+    sd["logit_scale"] = torch.tensor(3.0)          # sharper softmax than the 1/0.07 init on random features
+    m.logit_scale.data.fill_(3.0)
+    img = S.synthetic_images(3, cfg.image_resolution, seed=4)
+    txt = S.synthetic_tokens(7, cfg.context_length, cfg.vocab_size, seed=5, min_len=2)
+    scores, idx, probs = zero_shot(m, img.to(DEV), txt.to(DEV))
+    fi, ft = O.encode_image(sd, cfg, img), O.encode_text(sd, cfg, txt)
+    lpi, _ = O.logits_from_features(fi, ft, sd["logit_scale"], True)
+    ref = lpi.softmax(dim=-1)
+    assert tuple(probs.shape) == (3, 7) and not any(p.grad is not None for p in m.parameters())
+    assert float((probs.cpu() - ref).abs().max()) < 2e-2
+    assert torch.equal(idx.cpu(), ref.argmax(dim=-1))
+    assert float((scores.cpu() - ref.max(dim=-1).values).abs().max()) < 2e-2
+
+
 def test_ot_alignment_against_reference_golden():
     """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
     recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""
