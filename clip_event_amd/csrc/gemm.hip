@@ -87,6 +87,27 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4
     }
 }
 
+// Fused bias gradient of the GELUGRAD epilogue: every lane holds partial column sums of its 8 columns
+// (n_local .. n_local+7 of the workgroup's 256-column tile); the 8 row-phases of a wave and the two waves stacked
+// along M share columns.  Each lane parks its 8 partial sums in a [16][256] LDS strip (plain 16-byte stores, row =
+// 8*wm + row-phase), then thread c adds column c's 16 entries and issues the workgroup's ONE global atomic for
+// that column: 4 atomic wave-instructions per workgroup instead of 64, no cross-lane shuffles.
+__device__ __forceinline__ void wg_colsum_flush(char* smem, float* __restrict__ colsum, int n0, int N, int n_local,
+                                                int srow, const f32x4& cs0, const f32x4& cs1) {
+    constexpr int SROW = 264;                              // floats: 256 + 8 pad (rows shift by 8 banks)
+    float* strip = reinterpret_cast<float*>(smem);
+    __syncthreads();                                       // every wave is done with its epilogue slice
+    *reinterpret_cast<f32x4*>(strip + srow * SROW + n_local) = cs0;
+    *reinterpret_cast<f32x4*>(strip + srow * SROW + n_local + 4) = cs1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += strip[r * SROW + i];
+        if (n0 + i < N && t != 0.f) atomicAdd(colsum + n0 + i, t);
+    }
+}
+
 // fused epilogue for 8 consecutive output columns n..n+7 of row m (bias already added)
 template <int EPI>
 __device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4& cs0, f32x4& cs1) {
@@ -407,24 +428,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
         }
     }
     if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
-        if (p.out2) {   // fused bias gradient: reduce the 8 lanes that own the same 8 columns, one atomic per column per wave
-            float* colsum = reinterpret_cast<float*>(p.out2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    cs0[e] += __shfl_xor(cs0[e], o, 64);
-                    cs1[e] += __shfl_xor(cs1[e], o, 64);
-                }
-            }
-            if (lane < 8 && gn < p.N) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(colsum + gn + e, cs0[e]);
-                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
-                }
-            }
-        }
+        if (p.out2) wg_colsum_flush(smem, reinterpret_cast<float*>(p.out2), n0, p.N, gn - n0, wm * 8 + e_r, cs0, cs1);   // block-uniform
     }
 }
 
@@ -692,24 +696,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt32_kernel(NTArgs p) {
         }
     }
     if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
-        if (p.out2) {   // fused bias gradient: reduce the 8 lanes that own the same 8 columns, one atomic per column per wave
-            float* colsum = reinterpret_cast<float*>(p.out2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    cs0[e] += __shfl_xor(cs0[e], o, 64);
-                    cs1[e] += __shfl_xor(cs1[e], o, 64);
-                }
-            }
-            if (lane < 8 && gn < p.N) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(colsum + gn + e, cs0[e]);
-                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
-                }
-            }
-        }
+        if (p.out2) wg_colsum_flush(smem, reinterpret_cast<float*>(p.out2), n0, p.N, gn - n0, wm * 8 + e_r, cs0, cs1);   // block-uniform
     }
 }
 

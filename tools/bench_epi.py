@@ -6,7 +6,18 @@ import torch
 from clip_event_amd import ops, _lib as L
 from tools.bench_ops import timeit
 DEV = "cuda:0"
-for name, M, N, K in [("v.fc", 12800, 3072, 768), ("v.proj", 12800, 768, 3072), ("t.fc", 19712, 2048, 512), ("v.out", 12800, 768, 768)]:
+from ctypes import c_int, c_long
+from clip_event_amd._lib import check, lib, ptr, stream
+
+
+def gelugrad_colsum(a, b, aux, out, cs):
+    M, K = a.shape
+    N = b.shape[0]
+    check(lib().ce_gemm_nt(ptr(a), c_long(K), ptr(b), c_long(K), c_int(M), c_int(N), c_int(K), c_int(L.EPI_GELUGRAD_BF16),
+                           None, None, c_long(0), ptr(out), c_long(N), ptr(cs), c_long(N), ptr(aux), c_long(N), stream()), "nt")
+
+
+for name, M, N, K in [("v.fc", 12800, 3072, 768), ("v.proj", 12800, 768, 3072), ("t.fc", 11137, 2048, 512), ("v.out", 12800, 768, 768)]:
     a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
     b = (torch.randn(N, K, device=DEV) * K ** -0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=DEV)
@@ -14,11 +25,13 @@ for name, M, N, K in [("v.fc", 12800, 3072, 768), ("v.proj", 12800, 768, 3072), 
     aux = torch.randn(M, N, device=DEV).to(torch.bfloat16)
     o16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); o16b = torch.empty_like(o16)
     o32 = torch.empty(M, N, device=DEV)
+    cs = torch.zeros(N, device=DEV)
     for en, fn in [("BF16", lambda: ops.gemm_nt(a, b, L.EPI_BF16, out=o16)),
                    ("BIAS_BF16", lambda: ops.gemm_nt(a, b, L.EPI_BIAS_BF16, bias=bias, out=o16)),
                    ("F32", lambda: ops.gemm_nt(a, b, L.EPI_F32, out=o32)),
                    ("RESID", lambda: ops.gemm_nt(a, b, L.EPI_BIAS_RESID_F32, bias=bias, resid=resid, out=o32)),
                    ("GELU", lambda: ops.gemm_nt(a, b, L.EPI_BIAS_GELU, bias=bias, out=o16, out2=o16b)),
-                   ("GELUGRAD", lambda: ops.gemm_nt(a, b, L.EPI_GELUGRAD_BF16, aux=aux, out=o16))]:
+                   ("GELUGRAD", lambda: ops.gemm_nt(a, b, L.EPI_GELUGRAD_BF16, aux=aux, out=o16)),
+                   ("GELUGRAD+cs", lambda: gelugrad_colsum(a, b, aux, o16, cs))]:
         t = timeit(fn)
         print(f"{name:7s} {en:10s} {t*1e6:8.1f} us {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
