@@ -330,14 +330,24 @@ class CLIP(nn.Module):
             self._flat_grad.zero_()
             for n, p in todo:
                 p.grad = self._gview(n)
-            return
-        for n, p in todo:
-            view = self._gview(n)
-            if p.grad is None:
-                view.zero_()
-            else:
-                view.copy_(p.grad)
-            p.grad = view
+        else:
+            for n, p in todo:
+                view = self._gview(n)
+                if p.grad is None:
+                    view.zero_()
+                else:
+                    view.copy_(p.grad)
+                p.grad = view
+        # The fills above ran on the stream of whichever backward node came first (a tower's side stream).  The
+        # other tower's backward writes the same buffer from ITS stream: order it behind the fills, or its first
+        # weight gradients land before the zero-fill and are wiped.
+        cur = torch.cuda.current_stream()
+        for s_ in (getattr(self, "_side_streams", None) or ()):
+            if s_ != cur:
+                s_.wait_stream(cur)
+        ms = getattr(self, "_main_stream", None)
+        if ms is not None and ms != cur:
+            ms.wait_stream(cur)
 
     def zero_grad(self, set_to_none: bool = False):  # noqa: D401 - nn.Module API
         if self._flat_grad is not None and not set_to_none:

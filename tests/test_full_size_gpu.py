@@ -1,0 +1,99 @@
+"""BASELINE.json's full sizes (ViT-B/32, per-GPU batch 256, 77-token captions) checked through size-independent
+properties -- the CPU oracle cannot run them in seconds.  The small-size oracle / golden comparisons are in
+test_model_gpu.py; here the SAME code path is exercised at the benchmarked shape."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vitb32():
+    from oracle import clip_oracle as O
+    from clip_event_amd.model import build_model
+    return build_model(O.init_params(O.VIT_B32, 0)).to(DEV)
+
+
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_batch_permutation_equivariance_and_logit_symmetry(vitb32):
+    """Every sample is processed independently until the logits, and a row's arithmetic does not depend on where it
+    sits in a tile: features of a permuted batch are the permuted features BIT FOR BIT (images: dense rows; captions:
+    packed rows move to different offsets and lengths).  K = 1 over-batch logits are each other's transposes."""
+    from clip_event_amd import synthetic as S
+    m = vitb32
+    B = 256
+    img = S.synthetic_images(B, 224, seed=999).to(DEV)
+    txt = S.synthetic_tokens(B, 77, 49408, seed=999).to(DEV)
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(B)).to(DEV)
+    with torch.no_grad():
+        fi, ft = m.encode_both(img, txt)
+        fi_p, ft_p = m.encode_both(img[perm].contiguous(), txt[perm].contiguous())
+        lpi, lpt = m(img, txt)
+    torch.cuda.synchronize()
+    assert torch.equal(fi_p, fi[perm]), "image features are not permutation-equivariant bit for bit"
+    assert torch.equal(ft_p, ft[perm]), "text features are not permutation-equivariant bit for bit"
+    assert tuple(lpi.shape) == (B, B) and bool(torch.isfinite(lpi).all())
+    assert float((lpi - lpt.t()).abs().max()) < 1e-3 * float(lpi.abs().max())
+    # unit-norm rows behind the logits: |logit| <= exp(logit_scale)
+    assert float(lpi.abs().max()) <= float(m.logit_scale.detach().exp()) * (1 + 1e-5)
+
+
+def test_full_size_step_packed_equals_dense(vitb32):
+    """One full training-shaped forward + backward at B = 256 with the text tower on live tokens vs on all 77
+    positions: same loss, same gradients (tile-order rounding only), and the packed run's caption rows after the
+    EOT really are absent (rows < B*77)."""
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.functional import text_packing
+    from clip_event_amd.losses import CriterionContrastive
+    m = vitb32
+    B = 256
+    img = S.synthetic_images(B, 224, seed=7).to(DEV)
+    txt = S.synthetic_tokens(B, 77, 49408, seed=7).to(DEV)
+    y = torch.arange(B, device=DEV)
+    crit = CriterionContrastive("ce")
+    out = {}
+    for packed in (True, False):
+        m.pack_text = packed
+        m.zero_grad(set_to_none=True)
+        ld = crit(*m(img, txt), y, y, index_pos=y)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        out[packed] = (float(ld["loss_i"]), float(ld["loss_t"]), m._flat_grad.detach().clone())
+    m.pack_text = True
+    pk = text_packing(m, txt)
+    assert pk.rows == int((txt.argmax(dim=-1) + 1).sum()) and pk.rows < B * 77
+    (li_p, lt_p, g_p), (li_d, lt_d, g_d) = out[True], out[False]
+    assert abs(li_p - li_d) < 1e-4 and abs(lt_p - lt_d) < 1e-4
+    assert bool(torch.isfinite(g_p).all()) and float(g_p.norm()) > 0
+    assert _rel(g_p, g_d) < 2e-3, _rel(g_p, g_d)
+    # per tower as well (a tower-level slip would hide in the total)
+    for name, (a, b) in m._ranges.items():
+        if b > a and float(g_d[a:b].norm()) > 0:
+            assert _rel(g_p[a:b], g_d[a:b]) < 3e-3, (name, _rel(g_p[a:b], g_d[a:b]))
+
+
+def test_full_size_hard_negative_rows(vitb32):
+    """Config c3's shape on one GPU at reduced batch (B = 64 images x K = 5 descriptions = 320 captions): the logits of
+    the full [B, B*K] problem restricted to a sub-batch equal the sub-batch run alone (rows are independent), and the
+    positive-row logits_per_text block matches index_pos."""
+    from clip_event_amd import synthetic as S
+    from clip_event_amd import distributed as D
+    m = vitb32
+    B, K = 64, 5
+    img = S.synthetic_images(B, 224, seed=3).to(DEV)
+    txt = S.synthetic_tokens(B * K, 77, 49408, seed=4).to(DEV)
+    yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=DEV, rank_=0)
+    assert yi.tolist()[:3] == [0, 5, 10] and ip.tolist()[:3] == [0, 5, 10] and yt.tolist()[:6] == [0, 0, 0, 0, 0, 1]
+    with torch.no_grad():
+        lpi, lpt = m(img, txt)
+        sub = slice(0, 16)
+        lpi_s, lpt_s = m(img[sub].contiguous(), txt[:16 * K].contiguous())
+    assert tuple(lpi.shape) == (B, B * K) and tuple(lpt.shape) == (B * K, B)
+    assert float((lpi[sub, :16 * K] - lpi_s).abs().max()) < 2e-3
+    assert float((lpt[:16 * K, sub] - lpt_s).abs().max()) < 2e-3
