@@ -137,6 +137,26 @@ int ce_copy_rows(const void* src, long src_stride_bytes, const int* src_rows, vo
 /* rows[r] = r*tokens + argmax_t ids[r,t]  (EOT gather index, model_clip.py:415; first maximum) */
 int ce_eot_rows(const int64_t* ids, int* rows, long n, int tokens, void* stream);
 
+/* ---- image preprocessing (preprocess.hip) ---- */
+/* One entry per OUTPUT image (several may share a source: whole image + object patches, dataset_voa.py:195-233).
+ * Geometry is torchvision's Resize(n)/CenterCrop(n) on the region (x0,y0,w,h) of an HWC uint8 RGB image; the host
+ * fills it (clip_event_amd/preprocess.py).  row0/rows = the region rows the vertical pass reads. */
+typedef struct {
+    const unsigned char* src;  /* device pointer, HWC uint8 RGB */
+    long pitch;                /* bytes per source row */
+    int x0, y0, w, h;          /* region = image.crop((x0, y0, x0+w, y0+h)), inside the image */
+    int ow, oh;                /* size after Resize(n): shorter side n */
+    int left, top;             /* CenterCrop offsets in the resized image */
+    int row0, rows;            /* first region row and row count needed by the n cropped output rows */
+    long tmp_off;              /* byte offset of this output's [rows][n][3] block in the scratch buffer */
+} ce_preproc_desc;
+size_t ce_preprocess_table_bytes(int n_out, int n_px, int kmax);
+/* out[o] (f32 [3,n,n]) = Normalize(ToTensor(CenterCrop(Resize(region_o, BICUBIC)))), clip.py:62-69, bit-exact with
+ * Pillow's resampling.  kmax >= 2*ceil(2*max_scale)+1 taps; table = ce_preprocess_table_bytes(); tmp = sum of
+ * rows*n*3 bytes; mean/std = HOST pointers to 3 floats. */
+int ce_preprocess(const ce_preproc_desc* descs_device, int n_out, int n_px, int kmax, int max_rows, void* table,
+                  void* tmp, float* out, const float* mean, const float* std, void* stream);
+
 /* ---- contrastive head (head.hip) ---- */
 int ce_l2norm_fwd(const float* f, long ldf, float* y, long ldy, float* inv_norm, int n, int E, void* stream);
 int ce_l2norm_bwd(const float* dy, long lddy, const float* y, long ldy, const float* inv_norm, float* df, long lddf,
