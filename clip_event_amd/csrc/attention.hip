@@ -371,6 +371,340 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sequences longer than 128 tokens (ViT-B/16: 197, ViT-L/14: 257 / 577 at 336 px): the same fragment maps, tiled
+// flash-style over 64-key blocks with an online softmax.  One workgroup = 4 waves = 64 queries (forward, dQ) or 64
+// keys (dK / dV); K / V (Q / dO) blocks pass through LDS, nothing of size L x L is ever stored.  The backward is two
+// kernels so that no gradient needs atomics: A recomputes P per (query block, key block) and accumulates dQ over the
+// key blocks; B owns a key block and accumulates dK, dV over the query blocks.
+// ------------------------------------------------------------------------------------------
+constexpr int LB = 64;                 // rows per block
+constexpr int LPROW = LB * 2 + 32;     // P / dS image row stride (bytes)
+
+__device__ __forceinline__ void stage_block(char* dst, const bf16_t* src, long ld, int row0, int L, int tid) {
+    // 64 rows x 64 bf16 = 512 16-byte chunks, 256 threads; rows >= L zero-filled
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + c * 256;
+        const int r = idx >> 3, ch = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + r < L) v = *reinterpret_cast<const u32x4*>(src + (long)(row0 + r) * ld + ch * 8);
+        *reinterpret_cast<u32x4*>(dst + r * ROW + ch * 16) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
+                                                            long ldo, float* __restrict__ lse, int L, int H, int D,
+                                                            int causal, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW];
+    char* sK = smem;
+    char* sV = smem + LB * ROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
+    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
+    const int li = lane & 15, g = lane >> 4;
+    const int i = qb * LB + wave * 16 + li;
+    const int iq = min(i, L - 1);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb_all = (L + LB - 1) / LB;
+    const int nkb = causal ? min(nkb_all, qb + 1) : nkb_all;
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb) __syncthreads();
+        stage_block(sK, base + D, ld, kb * LB, L, tid);
+        stage_block(sV, base + 2 * D, ld, kb * LB, L, tid);
+        __syncthreads();
+        f32x4 s[4];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kb * LB + t * 16 + g * 4 + r;
+                const bool ok = (j < L) && (!causal || j <= i);
+                s[t][r] = ok ? s[t][r] * scale : -INFINITY;
+                bm = fmaxf(bm, s[t][r]);
+            }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);                        // finite from the first block on: key 0 is never masked
+        const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = (mn == -INFINITY) ? 0.f : __expf(s[t][r] - mn);
+                sum += s[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * alpha + sum;
+        m = mn;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] *= alpha;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            bf16x8 pf = pack8(s[2 * sidx], s[2 * sidx + 1]);
+            const char* vrow = sV + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 vf = tr_pair(vrow + ct * 32, vrow + ct * 32 + 16 * ROW);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+    if (i < L) {
+        const float inv = 1.0f / l;
+        bf16_t* orow = o + ((long)b * L + i) * ldo + h * HD + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            u32x2 pk = {pack_bf2(acc[ct][0] * inv, acc[ct][1] * inv), pack_bf2(acc[ct][2] * inv, acc[ct][3] * inv)};
+            *reinterpret_cast<u32x2*>(orow + ct * 16) = pk;
+        }
+        if (g == 0) lse[((long)b * H + h) * L + i] = m + __logf(l);
+    }
+}
+
+// per-query operands of a 16-query strip: B fragments of Q and dO, log-sum-exp, delta = sum_c dO O
+struct StripOps {
+    bf16x8 qf[2], df[2];
+    float lse, dl;
+};
+__device__ __forceinline__ StripOps load_strip(const bf16_t* base, long ld, const bf16_t* dob, long lddo, const bf16_t* ob,
+                                               long ldo, const float* lse_row, int iq, int g) {
+    StripOps s;
+    float dl = 0.f;
+    const u32x4* pd = reinterpret_cast<const u32x4*>(dob + (long)iq * lddo + g * 16);
+    const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)iq * ldo + g * 16);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        u32x4 a = pd[v], c = po[v];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dl += bf_lo(a[e]) * bf_lo(c[e]) + bf_hi(a[e]) * bf_hi(c[e]);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    s.dl = dl;
+    s.lse = lse_row[iq];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        s.qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+        s.df[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)iq * lddo + ks * 32 + g * 8);
+    }
+    return s;
+}
+
+// P^T and dS^T of one 16-query strip against the 64 keys staged in sK / sV (accumulator layout: key 16t + 4g + r)
+__device__ __forceinline__ void strip_p_ds(const char* sK, const char* sV, const StripOps& q, int i, bool iok, int key0, int L,
+                                           int causal, float scale, int li, int g, f32x4 (&p)[4], f32x4 (&ds)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+            bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q.qf[ks], p[t], 0, 0, 0);
+            ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, q.df[ks], ds[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = key0 + t * 16 + g * 4 + r;
+            const bool ok = iok && (j < L) && (!causal || j <= i);
+            const float pv = ok ? __expf(p[t][r] * scale - q.lse) : 0.f;
+            p[t][r] = pv;
+            ds[t][r] = pv * (ds[t][r] - q.dl) * scale;
+        }
+    }
+}
+
+// backward A: dQ (and its bias column sums), one workgroup per 64-query block
+__global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                               const bf16_t* __restrict__ o, long ldo,
+                                                               const bf16_t* __restrict__ dout, long lddo,
+                                                               const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                               long lddq, float* __restrict__ bias_grad, int L, int H, int D,
+                                                               int causal, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW + 64 * 4];
+    char* sK = smem;
+    char* sV = smem + LB * ROW;
+    float* csum = reinterpret_cast<float*>(smem + 2 * LB * ROW);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
+    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
+    const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
+    const bf16_t* ob = o + (long)b * L * ldo + h * HD;
+    bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
+    const int li = lane & 15, g = lane >> 4;
+    const int i = qb * LB + wave * 16 + li;
+    const bool iok = i < L;
+    const int iq = min(i, L - 1);
+    if (tid < 64) csum[tid] = 0.f;
+    const StripOps q = load_strip(base, ld, dob, lddo, ob, ldo, lse + ((long)b * H + h) * L, iq, g);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb_all = (L + LB - 1) / LB;
+    const int nkb = causal ? min(nkb_all, qb + 1) : nkb_all;
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb) __syncthreads();
+        stage_block(sK, base + D, ld, kb * LB, L, tid);
+        stage_block(sV, base + 2 * D, ld, kb * LB, L, tid);
+        __syncthreads();
+        f32x4 p[4], ds[4];
+        strip_p_ds(sK, sV, q, i, iok, kb * LB, L, causal, scale, li, g, p, ds);
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {                 // dQ^T += K^T dS^T
+            bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
+            const char* krow = sK + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 kf = tr_pair(krow + ct * 32, krow + ct * 32 + 16 * ROW);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+    if (iok) {
+        bf16_t* qrow = dbase + (long)i * lddq + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            u32x2 pk = {pack_bf2(acc[ct][0], acc[ct][1]), pack_bf2(acc[ct][2], acc[ct][3])};
+            *reinterpret_cast<u32x2*>(qrow + ct * 16) = pk;
+        }
+    }
+    if (bias_grad) {                                           // block-uniform
+        float vals[16];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vals[ct * 4 + r] = acc[ct][r];
+        const float tot = row16_colsum(vals, li);
+        const int k = row16_colsum_index(li);
+        __syncthreads();                                       // csum zeroed
+        atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tot);
+        __syncthreads();
+        if (tid < 64) atomicAdd(bias_grad + h * HD + tid, csum[tid]);
+    }
+}
+
+// backward B: dK, dV (and their bias column sums), one workgroup per 64-key block
+__global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                                const bf16_t* __restrict__ o, long ldo,
+                                                                const bf16_t* __restrict__ dout, long lddo,
+                                                                const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                                long lddq, float* __restrict__ bias_grad, int L, int H, int D,
+                                                                int causal, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * LB * ROW + 2 * LB * LPROW + 128 * 4];
+    char* sK = smem;
+    char* sV = sK + LB * ROW;
+    char* sQ = sV + LB * ROW;
+    char* sDO = sQ + LB * ROW;
+    char* sP = sDO + LB * ROW;
+    char* sDS = sP + LB * LPROW;
+    float* csum = reinterpret_cast<float*>(sDS + LB * LPROW);   // [2][64]: dk | dv
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
+    const bf16_t* base = qkv + (long)b * L * ld + h * HD;
+    const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
+    const bf16_t* ob = o + (long)b * L * ldo + h * HD;
+    bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
+    const float* lse_row = lse + ((long)b * H + h) * L;
+    const int li = lane & 15, g = lane >> 4;
+    if (tid < 128) csum[tid] = 0.f;
+    stage_block(sK, base + D, ld, kb * LB, L, tid);
+    stage_block(sV, base + 2 * D, ld, kb * LB, L, tid);
+    f32x4 av[4], ak[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        av[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ak[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nqb = (L + LB - 1) / LB;
+    for (int qb = causal ? kb : 0; qb < nqb; ++qb) {
+        __syncthreads();                                       // previous block's images / Q / dO consumed (and K, V staged)
+        stage_block(sQ, base, ld, qb * LB, L, tid);
+        stage_block(sDO, dob, lddo, qb * LB, L, tid);
+        {   // P / dS images [query][key] of this (query block, key block) pair: wave = 16-query strip
+            const int i = qb * LB + wave * 16 + li;
+            const bool iok = i < L;
+            const StripOps q = load_strip(base, ld, dob, lddo, ob, ldo, lse_row, min(i, L - 1), g);
+            f32x4 p[4], ds[4];
+            strip_p_ds(sK, sV, q, i, iok, kb * LB, L, causal, scale, li, g, p, ds);
+            const int il = wave * 16 + li;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                u32x2 pk = {pack_bf2(p[t][0], p[t][1]), pack_bf2(p[t][2], p[t][3])};
+                u32x2 dk = {pack_bf2(ds[t][0], ds[t][1]), pack_bf2(ds[t][2], ds[t][3])};
+                *reinterpret_cast<u32x2*>(sP + il * LPROW + (t * 16 + g * 4) * 2) = pk;
+                *reinterpret_cast<u32x2*>(sDS + il * LPROW + (t * 16 + g * 4) * 2) = dk;
+            }
+        }
+        __syncthreads();
+        // wave = 16-key tile: dV^T += dO^T P, dK^T += Q^T dS over the block's 64 queries
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int irow = 32 * sidx + 8 * g + (li >> 2);
+            const char* pcol = sP + irow * LPROW + (wave * 16 + 4 * (li & 3)) * 2;
+            const char* scol = sDS + irow * LPROW + (wave * 16 + 4 * (li & 3)) * 2;
+            bf16x8 pf = tr_pair(pcol, pcol + 4 * LPROW);
+            bf16x8 sf = tr_pair(scol, scol + 4 * LPROW);
+            const int roff = irow * ROW + (4 * (li & 3)) * 2;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x8 dof = tr_pair(sDO + roff + ct * 32, sDO + roff + ct * 32 + 4 * ROW);
+                bf16x8 qf = tr_pair(sQ + roff + ct * 32, sQ + roff + ct * 32 + 4 * ROW);
+                av[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, av[ct], 0, 0, 0);
+                ak[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[ct], 0, 0, 0);
+            }
+        }
+    }
+    const int j = kb * LB + wave * 16 + li;
+    if (j < L) {
+        bf16_t* krow = dbase + (long)j * lddq + D + 4 * g;
+        bf16_t* vrow = dbase + (long)j * lddq + 2 * D + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            u32x2 pk = {pack_bf2(ak[ct][0], ak[ct][1]), pack_bf2(ak[ct][2], ak[ct][3])};
+            u32x2 pv = {pack_bf2(av[ct][0], av[ct][1]), pack_bf2(av[ct][2], av[ct][3])};
+            *reinterpret_cast<u32x2*>(krow + ct * 16) = pk;
+            *reinterpret_cast<u32x2*>(vrow + ct * 16) = pv;
+        }
+    }
+    if (bias_grad) {
+        float vk[16], vv[16];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vk[ct * 4 + r] = ak[ct][r];
+                vv[ct * 4 + r] = av[ct][r];
+            }
+        const float tk = row16_colsum(vk, li), tv = row16_colsum(vv, li);
+        const int k = row16_colsum_index(li);
+        atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tk);
+        atomicAdd(&csum[64 + (k >> 2) * 16 + 4 * g + (k & 3)], tv);
+        __syncthreads();
+        if (tid < 128) atomicAdd(bias_grad + (1 + (tid >> 6)) * D + h * HD + (tid & 63), csum[tid]);
+    }
+}
+
 int tiles_for(int L) { return ((L + 31) / 32) * 2; }
 
 }  // namespace
@@ -381,7 +715,7 @@ int tiles_for(int L) { return ((L + 31) / 32) * 2; }
         case 4: CALL(4); break;                \
         case 6: CALL(6); break;                \
         case 8: CALL(8); break;                \
-        default: CE_CHECK_ARG(false, "attention: sequence length %d not supported (max 128)", L); \
+        default: CE_CHECK_ARG(false, "attention: sequence length %d not supported", L); \
     }
 
 extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, float* lse, const int* cu_seqlens, int B,
@@ -389,6 +723,16 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
     CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_fwd: empty problem");
     CE_CHECK_ARG(ld % 8 == 0 && ldo % 4 == 0, "ce_attention_fwd: ld must be a multiple of 8, ldo of 4");
     const int D = H * HD;
+    if (L > 128) {
+        CE_CHECK_ARG(!cu_seqlens, "ce_attention_fwd: packed batches are limited to 128 tokens per sample");
+        CE_CHECK_ARG((long)B * H <= 65535, "ce_attention_fwd: B*H = %ld exceeds the grid", (long)B * H);
+        hipStream_t sl = (hipStream_t)stream;
+        CeProfScope prof(CE_PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (4.0 * D), sl);
+        hipLaunchKernelGGL(attn_fwd_long_kernel, dim3((L + LB - 1) / LB, B * H), dim3(256), 0, sl, (const bf16_t*)qkv, ld,
+                           (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f);
+        CE_LAUNCH_CHECK();
+        return 0;
+    }
     const int T = tiles_for(L);
     const int Lp = T * 16;
     int nw = (L + 15) / 16;
@@ -412,6 +756,19 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
     CE_CHECK_ARG(B > 0 && L > 0 && H > 0, "ce_attention_bwd: empty problem");
     CE_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0, "ce_attention_bwd: bad leading dimension");
     const int D = H * HD;
+    if (L > 128) {
+        CE_CHECK_ARG(!cu_seqlens, "ce_attention_bwd: packed batches are limited to 128 tokens per sample");
+        CE_CHECK_ARG((long)B * H <= 65535, "ce_attention_bwd: B*H = %ld exceeds the grid", (long)B * H);
+        hipStream_t sl = (hipStream_t)stream;
+        CeProfScope prof(CE_PROF_ATTN_BWD, 14.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (8.0 * D), sl);
+        const dim3 grid((L + LB - 1) / LB, B * H);
+        hipLaunchKernelGGL(attn_bwd_long_dq_kernel, grid, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
+                           (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+        hipLaunchKernelGGL(attn_bwd_long_dkv_kernel, grid, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
+                           (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+        CE_LAUNCH_CHECK();
+        return 0;
+    }
     const int T = tiles_for(L);
     const int Lp = T * 16;
     int nw = T;

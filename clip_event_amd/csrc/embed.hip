@@ -123,6 +123,17 @@ __global__ void pos_embed_bwd_packed_kernel(const float* __restrict__ dx0, const
         if (acc[e] != 0.f) atomicAdd(dpos + (long)t * D + c + e, acc[e]);
 }
 
+// dst[r, c] += src[r, c], c < cols (row strides differ: real columns of a column-padded gradient)
+__global__ void add_cols_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, int rows,
+                                int cols) {
+    const long total = (long)rows * cols;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / cols;
+        const int c = (int)(idx - r * cols);
+        dst[r * ldd + c] += src[r * lds + c];
+    }
+}
+
 // out[t, c] (+)= sum_b x[b, t, c]  over `B` slabs of `slab` floats, rows [row0, row0+nrows) of each slab
 __global__ void batch_reduce_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long slab, long n,
                                     int accumulate) {
@@ -335,6 +346,14 @@ extern "C" int ce_cast_transpose(const float* w, void* w16, long ld16, void* w16
     CE_CHECK_ARG(R > 0 && C > 0, "ce_cast_transpose: bad shape");
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(ce_div_up(C, 32), ce_div_up(R, 32)), dim3(256), 0, (hipStream_t)stream,
                        w, (bf16_t*)w16, ld16, (bf16_t*)w16t, ld16t, R, C);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_add_cols(const float* src, long lds, float* dst, long ldd, int rows, int cols, void* stream) {
+    CE_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "ce_add_cols: bad shape");
+    hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for((long)rows * cols)), dim3(256), 0, (hipStream_t)stream, src, lds, dst,
+                       ldd, rows, cols);
     CE_LAUNCH_CHECK();
     return 0;
 }

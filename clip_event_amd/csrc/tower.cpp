@@ -129,7 +129,7 @@ int check_desc(const ce_tower_desc* d, int batch) {
     CE_CHECK_ARG(d && d->blocks, "tower: null descriptor");
     CE_CHECK_ARG(d->layers > 0 && d->layers <= Layout::MAX_LAYERS, "tower: layers=%d out of range", d->layers);
     CE_CHECK_ARG(d->width == d->heads * 64, "tower: width %d != heads %d * 64", d->width, d->heads);
-    CE_CHECK_ARG(d->tokens > 0 && d->tokens <= 128, "tower: tokens=%d unsupported (1..128)", d->tokens);
+    CE_CHECK_ARG(d->tokens > 0 && d->tokens <= 4096, "tower: tokens=%d unsupported (1..4096)", d->tokens);
     CE_CHECK_ARG(batch > 0, "tower: empty batch");
     return 0;
 }

@@ -217,9 +217,17 @@ class EncodeImageFn(torch.autograd.Function):
         # conv1 weight gradient: dW[width, 3*p*p] += dpatch^T patches   (no input gradient is ever needed)
         dpatch = _empty((B * g * g, D), torch.bfloat16, dev)
         check(cl.ce_vision_assemble_bwd(ptr(dxpre), ptr(dpatch), c_int(B), c_int(T), c_int(D), s), "ce_vision_assemble_bwd")
-        check(cl.ce_gemm_tn(ptr(dpatch), c_long(D), ptr(patches), c_long(model._kp), c_int(B * g * g), c_int(D),
-                            c_int(model._kp), ptr(G("visual.conv1.weight")), c_long(model._kp), c_int(0), s),
-              "ce_gemm_tn(conv1)")
+        if model._conv_pad is None:
+            check(cl.ce_gemm_tn(ptr(dpatch), c_long(D), ptr(patches), c_long(model._kp), c_int(B * g * g), c_int(D),
+                                c_int(model._kp), ptr(G("visual.conv1.weight")), c_long(model._kp), c_int(0), s),
+                  "ce_gemm_tn(conv1)")
+        else:       # padded patch columns (model._build_device_tables): gradient through a padded scratch
+            gp = model._conv_gpad
+            gp.zero_()
+            check(cl.ce_gemm_tn(ptr(dpatch), c_long(D), ptr(patches), c_long(model._kp), c_int(B * g * g), c_int(D),
+                                c_int(model._kp), ptr(gp), c_long(model._kp), c_int(0), s), "ce_gemm_tn(conv1, padded)")
+            check(cl.ce_add_cols(ptr(gp), c_long(model._kp), ptr(G("visual.conv1.weight")), c_long(model._kp_real), c_int(D),
+                                 c_int(model._kp_real), s), "ce_add_cols(conv1)")
         if model.grad_sync is not None:
             model.grad_sync(model, "visual")
         _publish_to_main(ctx)

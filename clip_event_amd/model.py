@@ -382,10 +382,19 @@ class CLIP(nn.Module):
             self._w16t[n] = torch.empty(p.shape[1], p.shape[0], dtype=torch.bfloat16, device=dev)
         v = self.visual
         kp = 3 * v.patch_size * v.patch_size
-        if kp % 8 != 0:
-            raise NotImplementedError(f"patch size {v.patch_size}: 3*p*p must be a multiple of 8 for the bf16 patch GEMM")
-        self._kp = kp
-        self._w16["visual.conv1.weight"] = view16("visual.conv1.weight", (self.vision_width, kp))
+        self._kp_real = kp
+        if kp % 8 == 0:
+            self._kp = kp
+            self._conv_pad = None
+            self._w16["visual.conv1.weight"] = view16("visual.conv1.weight", (self.vision_width, kp))
+        else:
+            # patch 14 (ViT-L/14): 588 input columns.  The GEMM operands need 16-byte rows, so the patch matrix and
+            # a private bf16 copy of the weight are zero-padded to a multiple of 64 columns; the weight gradient is
+            # formed in a padded fp32 scratch and its real columns are added into the flat gradient buffer.
+            self._kp = (kp + 63) // 64 * 64
+            self._conv_pad = torch.zeros(self.vision_width, self._kp, dtype=torch.bfloat16, device=dev)
+            self._conv_gpad = torch.zeros(self.vision_width, self._kp, dtype=torch.float32, device=dev)
+            self._w16["visual.conv1.weight"] = self._conv_pad
         for n in ("visual.proj", "text_projection"):
             p = self._pmap[n]
             self._w16[n] = view16(n)                                                               # [width, E]
@@ -450,6 +459,9 @@ class CLIP(nn.Module):
             check(cl.ce_cast_bf16(ptr(self._flat), ptr(self._flat16), c_long(self._flat.numel()), s), "ce_cast_bf16")
         check(cl.ce_multi_transpose_bf16(ptr(self._tjobs), c_int(self._tjobs_n), c_int(self._tjobs_tiles), s),
               "ce_multi_transpose_bf16")
+        if self._conv_pad is not None:
+            check(cl.ce_cast_transpose(ptr(self._pmap["visual.conv1.weight"]), ptr(self._conv_pad), c_long(self._kp), None,
+                                       c_long(0), c_int(self.vision_width), c_int(self._kp_real), s), "ce_cast_transpose(conv1)")
         self._mirror_fresh = False
         self._versions = vers
 

@@ -92,7 +92,8 @@ int ce_layernorm_bwd(const void* dy, long lddy, int dy_f32, const float* x, long
 
 /* Self-attention core on the packed in-projection output qkv[B*L, 3*H*64] (bf16; q | k | v column
  * blocks, head h at columns h*64): o[B*L, H*64] = softmax(q k^T / 8 + causal?) v, lse[B*H*L] (f32)
- * saved for the backward.  L <= 128.  Replaces the core of nn.MultiheadAttention as called at
+ * saved for the backward.  L <= 128: one workgroup per (sample, head); longer sequences (ViT-B/16, ViT-L/14): tiled
+ * over 64-key blocks with an online softmax.  Replaces the core of nn.MultiheadAttention as called at
  * model_clip.py:188 (mask from model_clip.py:377-384).
  * cu_seqlens (int32 [B+1], nullable): variable-length batch, sample b owns rows cu_seqlens[b] ..
  * cu_seqlens[b+1]-1 (at most L of them); NULL = dense, sample b owns rows b*L .. b*L+L-1.  lse stays [B,H,L]. */
@@ -131,6 +132,8 @@ int ce_colsum_bf16(const void* x, long ld, float* out, int M, int N, void* strea
 /* fp32 master weight [R,C] -> bf16 copy [R,C] (nullable) and bf16 transposed copy [C,R] (nullable) */
 int ce_cast_transpose(const float* w, void* w16, long ld16, void* w16t, long ld16t, int R, int C, void* stream);
 int ce_cast_bf16(const float* x, void* y, long n, void* stream);
+/* dst[r,c] += src[r,c] for c < cols (rows with different strides: real columns of a column-padded gradient) */
+int ce_add_cols(const float* src, long lds, float* dst, long ldd, int rows, int cols, void* stream);
 /* gather / scatter whole rows: dst[dst_rows?dst_rows[i]:i] = src[src_rows?src_rows[i]:i], 16-byte granules */
 int ce_copy_rows(const void* src, long src_stride_bytes, const int* src_rows, void* dst, long dst_stride_bytes,
                  const int* dst_rows, int n, int row_bytes, void* stream);

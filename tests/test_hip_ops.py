@@ -172,6 +172,32 @@ def test_attention_fwd_bwd(B, L, H, causal):
         assert _report(f"attn {name} L={L}", dqkv[:, sl].float().cpu(), g[:, sl])[1] < 2e-2
 
 
+@pytest.mark.parametrize("B,L,H,causal", [(2, 197, 12, False), (1, 257, 4, False), (2, 577, 2, False), (3, 130, 2, True),
+                                          (1, 200, 1, True), (2, 129, 3, False), (1, 640, 1, True)])
+def test_attention_long_sequences(B, L, H, causal):
+    """L > 128 (ViT-B/16: 197, ViT-L/14: 257 / 577): flash-style tiled kernels, same tolerances as the short ones."""
+    from clip_event_amd import ops
+    rng = np.random.default_rng(B * 1000 + L)
+    D = H * 64
+    qkv = _randn(rng, B * L, 3 * D).to(torch.bfloat16)
+    qkv_r = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qkv_r, B, L, H, causal)
+    o, lse = ops.attention_fwd(qkv.to(DEV), B, L, H, causal)
+    torch.cuda.synchronize()
+    assert _report(f"long attn fwd o L={L}", o.float().cpu(), o_ref.detach())[1] < 1e-2
+    assert _report("long attn lse", lse.cpu().view(B, H, L), lse_ref.detach())[0] < 1e-3
+    dout = _randn(rng, B * L, D).to(torch.bfloat16)
+    o_ref.backward(dout.float())
+    bg = torch.zeros(3 * D, device=DEV)
+    dqkv = ops.attention_bwd(qkv.to(DEV), o, dout.to(DEV), lse, B, L, H, causal, bias_grad=bg)
+    torch.cuda.synchronize()
+    g = qkv_r.grad
+    assert bool(torch.isfinite(dqkv.float()).all())
+    assert _report(f"long attn in_proj bias grad L={L}", bg.cpu(), g.sum(0))[1] < 2e-2
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _report(f"long attn {name} L={L}", dqkv[:, sl].float().cpu(), g[:, sl])[1] < 2e-2
+
+
 @pytest.mark.parametrize("lens,Lmax,H,causal", [([77, 10, 33, 1, 64, 77, 17], 77, 8, True), ([5, 50, 32, 31], 50, 3, False),
                                                 ([128, 3, 96, 97], 128, 2, True), ([16], 20, 1, True)])
 def test_attention_packed_variable_length(lens, Lmax, H, causal):

@@ -131,6 +131,33 @@ def test_text_packing_matches_dense_layout():
     print(f"[packing] features rel {_rel(res[True][0], res[False][0]):.2e}, worst grad rel {worst:.2e}")
 
 
+def test_patch14_vision_tower_with_197_tokens():
+    """The ViT-L/14 / ViT-B/16 shape class: patch 14 (3*14*14 = 588 input columns, zero-padded for the GEMM) and
+    196 + 1 = 197 tokens per image (> 128: flash-style attention kernels), against the oracle."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    cfg = O.ClipConfig(64, 196, 2, 128, 14, 20, 512, 128, 2, 2)
+    assert cfg.vision_tokens == 197
+    m, sd = _mk(cfg, 13)
+    img = S.synthetic_images(3, cfg.image_resolution, seed=8)
+    w = torch.from_numpy(np.random.default_rng(1).standard_normal((3, cfg.embed_dim)).astype(np.float32))
+    f = m.encode_image(img.to(DEV))
+    (f * w.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    p_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    f_ref = O.encode_image(p_ref, cfg, img)
+    (f_ref * w).sum().backward()
+    f16 = O.encode_image(sd, cfg, img, bf16=True)
+    print(f"[patch14/197] features rel vs bf16-oracle {_rel(f.detach(), f16):.2e}, cos vs fp32 {_cos(f.detach(), f_ref.detach()):.6f}")
+    assert _rel(f.detach(), f16) < 5e-3 and _cos(f.detach(), f_ref.detach()) > 0.9995
+    worst = 1.0
+    for n, p in m.named_parameters():
+        if n.startswith("visual.") and p_ref[n].grad is not None and float(p_ref[n].grad.norm()) > 0:
+            worst = min(worst, _cos(p.grad, p_ref[n].grad))
+    print("[patch14/197] worst visual gradient cosine", worst)
+    assert worst > 0.98
+
+
 def test_vitb32_b8_against_reference_golden():
     """BASELINE config 1 on the GPU: ViT-B/32, batch 8, caption-only InfoNCE, vs the imported reference."""
     from oracle import clip_oracle as O
