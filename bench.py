@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU image batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--descriptions", type=int, default=1,
+                    help="descriptions per image K (1 positive + K-1 hard negatives, BASELINE config 3 uses 5); the "
+                         "headline metric is K = 1")
     ap.add_argument("--dense-text", action="store_true",
                     help="run the text tower on all 77 positions of every caption (default: live tokens SOT..EOT only; "
                          "the default run also reports this dense variant as config.dense_text)")
@@ -156,8 +159,9 @@ def main():
     opt = FusedAdam(model, lr=1e-6, weight_decay=0.0, max_norm=1.0)    # README.md:189-191 defaults
     sync = D.GradSync(model) if W > 1 else None
     img = S.synthetic_images(B, 224, seed=999 + rank).to(dev)
-    txt = S.synthetic_tokens(B, 77, 49408, seed=999 + rank).to(dev)
-    yi, yt, ip = D.global_labels(B, 1, 0, True, device=dev, rank_=rank)
+    K = max(1, args.descriptions)
+    txt = S.synthetic_tokens(B * K, 77, 49408, seed=999 + rank).to(dev)
+    yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=dev, rank_=rank)
 
     if args.dense_text:
         model.pack_text = False
@@ -192,7 +196,7 @@ def main():
     pairs_per_s = B * W * args.steps / dt
     # text rows the tower actually ran on (live tokens SOT..EOT) vs the dense [B, 77] layout
     lens = (txt.argmax(dim=-1) + 1).sum().item()
-    live_frac = 1.0 if args.dense_text else lens / float(B * 77)
+    live_frac = 1.0 if args.dense_text else lens / float(B * K * 77)
     dense = None
     if not args.dense_text and not args.no_dense_compare:      # the same step with every caption padded out to 77 rows, for comparison
         model.pack_text = False
@@ -250,9 +254,10 @@ def main():
                 "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
                 # nominal = SURVEY 8(d)'s 44.10 GFLOP/pair (all 77 text positions); executed = FLOPs actually issued
                 # (text-tower GEMM work scales with the live-row fraction)
-                "step_frac_of_bf16_peak": round(pairs_per_s / W * FLOP_PER_PAIR / PEAK_BF16, 4),
+                "step_frac_of_bf16_peak": round(pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR) / PEAK_BF16, 4),
                 "step_frac_of_bf16_peak_executed": round(
-                    pairs_per_s / W * (FLOP_PER_PAIR - TEXT_FLOP_PER_PAIR * (1.0 - live_frac)) / PEAK_BF16, 4),
+                    pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR
+                                       - K * TEXT_FLOP_PER_PAIR * (1.0 - live_frac)) / PEAK_BF16, 4),
                 "classes": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
     if W > 1:
         dist.barrier()
@@ -267,8 +272,8 @@ def main():
             "value": round(pairs_per_s, 2), "unit": "pairs/s (whole job)", "per_gpu": round(pairs_per_s / W, 2),
             "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=1, InfoNCE only, full train step "
-                                   "(fwd+bwd+clip_grad_norm+Adam), random-init weights" % B,
+            "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=%d, InfoNCE only, full train step "
+                                   "(fwd+bwd+clip_grad_norm+Adam), random-init weights" % (B, K),
                        "global_batch": B * W, "parallelism": "dp%d" % W, "loss": round(loss, 4),
                        "captions": "SOT + U[8,75] random ids + EOT, zero-padded to 77 (SURVEY 8(d) c2)",
                        "text_rows": ("all 77 positions" if args.dense_text else
