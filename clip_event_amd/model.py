@@ -499,7 +499,11 @@ class CLIP(nn.Module):
             self._main_stream = None
             return self.encode_image(image), self.encode_text(text)
         if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != self._flat.device:
-            self._side_streams = (torch.cuda.Stream(device=self._flat.device), torch.cuda.Stream(device=self._flat.device))
+            # the image tower is the longer chain: its stream gets the higher priority, the text tower's kernels fill
+            # in around it (measured 0.7 % on the step; CE_IMG_STREAM_PRIORITY / CE_TXT_STREAM_PRIORITY override)
+            pri = int(os.environ.get("CE_IMG_STREAM_PRIORITY", "-1"))
+            self._side_streams = (torch.cuda.Stream(device=self._flat.device, priority=pri),
+                                  torch.cuda.Stream(device=self._flat.device, priority=int(os.environ.get("CE_TXT_STREAM_PRIORITY", "0"))))
         s_img, s_txt = self._side_streams
         cur = torch.cuda.current_stream()
         self._main_stream = cur
