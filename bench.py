@@ -141,7 +141,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from oracle import clip_oracle as O              # only for the synthetic state dict + CPU baseline
     from clip_event_amd import synthetic as S
     from clip_event_amd import distributed as D
     from clip_event_amd._lib import lib
@@ -151,7 +150,7 @@ def main():
     from clip_event_amd.optim import FusedAdam
 
     B = args.batch
-    model = build_model(O.init_params(O.VIT_B32, 0)).to(dev)       # same weights on every rank
+    model = S.synthetic_model("vit_b32", seed=0).to(dev)         # same weights on every rank
     model.tower_streams = not args.single_stream
     if args.single_stream:
         lib().ce_tower_wgrad_stream(0)

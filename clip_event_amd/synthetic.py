@@ -63,3 +63,25 @@ def synthetic_bboxes(batch: int, seed: int = 999, max_roles: int = 4, none_frac:
             boxes.append((float(xs[0]), float(ys[0]), float(min(1.0, xs[1] + 1e-3)), float(min(1.0, ys[1] + 1e-3))))
         out.append(boxes)
     return out
+
+
+# CLIP constructor arguments (model_clip.py:267-286) of the geometries the benches use
+GEOMETRY = {
+    "vit_b32": (512, 224, 12, 768, 32, 77, 49408, 512, 8, 12),
+    "vit_b16": (512, 224, 12, 768, 16, 77, 49408, 512, 8, 12),
+    "vit_l14_336": (768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12),
+}
+
+
+def synthetic_model(geometry: str = "vit_b32", seed: int = 0):
+    """Random-init ``CLIP`` of a named geometry with the reference's own initialisation
+    (``CLIP.initialize_parameters``, model_clip.py:348-375) under a fixed CPU seed: the benches' weights (there is
+    no network for checkpoints).  The same weights on every rank and every box."""
+    from .model import CLIP
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        model = CLIP(*GEOMETRY[geometry])
+    finally:
+        torch.random.set_rng_state(state)
+    return model

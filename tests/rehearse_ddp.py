@@ -3,7 +3,7 @@
 parameter gradients of the HIP path must equal the single-process run on the concatenated batch.
 
     CE_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 \
-        --master-port 29511 tools/rehearse_ddp.py
+        --master-port 29511 tests/rehearse_ddp.py
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

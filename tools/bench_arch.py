@@ -4,29 +4,28 @@ ViT-B/16).  Not the headline metric: bench.py stays on ViT-B/32."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import clip_oracle as O
 from clip_event_amd import synthetic as S, distributed as D
 from clip_event_amd.engine import train_step
 from clip_event_amd.losses import CriterionContrastive
 from clip_event_amd.model import build_model
 from clip_event_amd.optim import FusedAdam
 
-ARCH = {
-    "vit_b16": (O.ClipConfig(512, 224, 12, 768, 16, 77, 49408, 512, 8, 12), 128, 3 * 2 * (17.58e9 / 2 + 2.9798e9)),
-    "vit_l14_336": (O.ClipConfig(768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12), 32, 1185.7e9),
+ARCH = {   # default batch, nominal fwd+bwd FLOP per pair
+    "vit_b16": (128, 3 * 2 * (17.58e9 + 2.9798e9)),
+    "vit_l14_336": (32, 1185.7e9),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "vit_l14_336"
-cfg, B, flop_pair = ARCH[name]
+B, flop_pair = ARCH[name]
 if len(sys.argv) > 2:
     B = int(sys.argv[2])
 dev = torch.device("cuda", 0)
 t0 = time.time()
-model = build_model(O.init_params(cfg, 0)).to(dev)
+model = S.synthetic_model(name, seed=0).to(dev)
 print(f"{name}: built in {time.time()-t0:.1f}s, {sum(p.numel() for p in model.parameters())/1e6:.0f} M parameters, "
-      f"{cfg.vision_tokens} image tokens", flush=True)
+      f"{model.visual.patch_num ** 2 + 1} image tokens", flush=True)
 crit = CriterionContrastive("ce")
 opt = FusedAdam(model, lr=1e-6)
-img = S.synthetic_images(B, cfg.image_resolution, seed=999).to(dev)
+img = S.synthetic_images(B, model.visual.input_resolution, seed=999).to(dev)
 txt = S.synthetic_tokens(B, 77, 49408, seed=999).to(dev)
 yi, yt, ip = D.global_labels(B, 1, 0, True, device=dev, rank_=0)
 for _ in range(2):

@@ -4,7 +4,6 @@ against the wall time including the final synchronise, and the host time of the 
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import clip_oracle as O
 from clip_event_amd import synthetic as S, distributed as D
 from clip_event_amd.engine import train_step
 from clip_event_amd.losses import CriterionContrastive
@@ -13,7 +12,7 @@ from clip_event_amd.optim import FusedAdam
 
 dev = torch.device("cuda", 0)
 B = 256
-model = build_model(O.init_params(O.VIT_B32, 0)).to(dev)
+model = S.synthetic_model("vit_b32", seed=0).to(dev)
 crit = CriterionContrastive("ce")
 opt = FusedAdam(model, lr=1e-6)
 img = S.synthetic_images(B, 224, seed=999).to(dev)

@@ -4,7 +4,6 @@ towards zero (fused clip + Adam, warm-up cosine schedule, packed text tower, two
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import clip_oracle as O
 from clip_event_amd import synthetic as S, distributed as D
 from clip_event_amd.engine import train_step
 from clip_event_amd.losses import CriterionContrastive
@@ -13,7 +12,7 @@ from clip_event_amd.optim import FusedAdam, WarmupCosineLR
 
 dev = torch.device("cuda", 0)
 B, STEPS = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 150
-model = build_model(O.init_params(O.VIT_B32, 0)).to(dev)
+model = S.synthetic_model("vit_b32", seed=0).to(dev)
 crit = CriterionContrastive("ce")
 opt = FusedAdam(model, lr=2e-5, weight_decay=0.0, max_norm=1.0)
 sch = WarmupCosineLR(opt, max_iters=STEPS, warmup_epochs=10)
