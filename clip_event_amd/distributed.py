@@ -5,7 +5,7 @@ InfoNCE over each rank's local batch (engine.py:48-53); its gradient-preserving
 ``gather_tensors`` helper (utils.py:192-206) has no caller.  BASELINE.json's north star asks for
 the *global*-batch loss, so this module provides
 
-* ``gather_features``: all-gather in rank order with a reduce-scatter(sum) backward, which makes
+* ``gather_features`` / ``gather_feature_pair``: all-gather in rank order with a reduce-scatter(sum) backward, which makes
   the W-rank gradient equal to the single-process gradient on the concatenated batch once the
   parameter gradients are averaged (SURVEY.md H3);
 * ``global_labels``: the label/index layout of dataset_voa.py:615-663 offset by ``rank*B``;
@@ -66,6 +66,18 @@ def gather_features(x: torch.Tensor) -> torch.Tensor:
     if world_size() == 1:
         return x
     return _AllGatherFn.apply(x)
+
+
+def gather_feature_pair(fi: torch.Tensor, ft: torch.Tensor):
+    """Both feature matrices of a step in ONE all-gather (and one reduce-scatter in the backward): the exchange is
+    latency-bound (a few hundred KB per rank), so two collectives cost twice one.  ``fi`` [B, E], ``ft`` [B*K, E] ->
+    ``(fi_all [W*B, E], ft_all [W*B*K, E])`` in rank order."""
+    W = world_size()
+    if W == 1:
+        return fi, ft
+    B, n = fi.shape[0], ft.shape[0]
+    both = gather_features(torch.cat([fi, ft], dim=0)).view(W, B + n, fi.shape[1])
+    return both[:, :B].reshape(W * B, -1), both[:, B:].reshape(W * n, -1)
 
 
 def global_labels(batch: int, num_pos: int = 1, num_neg: int = 0, overbatch: bool = True, device=None,

@@ -19,7 +19,7 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
     logits_per_text = s * T_local @ I_all^T with labels from ``distributed.global_labels``."""
     if D.world_size() > 1 and global_batch:
         fi, ft = model.encode_both(image, text)
-        fi_all, ft_all = D.gather_features(fi), D.gather_features(ft)
+        fi_all, ft_all = D.gather_feature_pair(fi, ft)
         overbatch = model.constrastive_overbatch
         lpi, _ = logits_from_features(fi, ft_all if overbatch else ft, model.logit_scale, overbatch, want="image")
         _, lpt = logits_from_features(fi_all, ft, model.logit_scale, True, want="text")

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, W, port, B, K, out):
+def _worker(rank, W, port, B, K, out, paired):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=W)
@@ -38,7 +38,7 @@ def _worker(rank, W, port, B, K, out):
     xt_all = torch.randn(W * B * K, 8, generator=g)
     xi, xt = xi_all[rank * B:(rank + 1) * B], xt_all[rank * B * K:(rank + 1) * B * K]
     fi, ft = xi @ Wi, xt @ Wt
-    fi_all, ft_all = D.gather_features(fi), D.gather_features(ft)
+    fi_all, ft_all = D.gather_feature_pair(fi, ft) if paired else (D.gather_features(fi), D.gather_features(ft))
     lpi, _ = O.logits_from_features(fi, ft_all, ls, True)          # local image rows x all texts
     _, lpt = O.logits_from_features(fi_all, ft, ls, True)          # local text rows x all images
     yi, yt, ip = D.global_labels(B, 1, K - 1, True, rank_=rank)
@@ -55,11 +55,12 @@ def _worker(rank, W, port, B, K, out):
 
 
 @pytest.mark.timeout(120)
-def test_global_batch_gradient_equals_single_process(tmp_path):
+@pytest.mark.parametrize("paired", [True, False])
+def test_global_batch_gradient_equals_single_process(tmp_path, paired):
     from oracle import clip_oracle as O
     W, B, K = 2, 3, 2
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(W, _free_port(), B, K, out), nprocs=W, join=True)
+    mp.spawn(_worker, args=(W, _free_port(), B, K, out, paired), nprocs=W, join=True)
     got = torch.load(out, weights_only=True)
     g = torch.Generator().manual_seed(7)
     E = 16
