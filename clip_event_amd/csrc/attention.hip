@@ -393,6 +393,27 @@ __device__ __forceinline__ void stage_block(char* dst, const bf16_t* src, long l
     }
 }
 
+// the same block in two steps: global -> registers (issued a block ahead, in flight during the MFMAs), registers -> LDS
+struct BlockRegs { u32x4 v[2]; };
+__device__ __forceinline__ BlockRegs load_block(const bf16_t* src, long ld, int row0, int L, int tid) {
+    BlockRegs b;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + c * 256;
+        const int r = idx >> 3, ch = idx & 7;
+        b.v[c] = u32x4{0u, 0u, 0u, 0u};
+        if (row0 + r < L) b.v[c] = *reinterpret_cast<const u32x4*>(src + (long)(row0 + r) * ld + ch * 8);
+    }
+    return b;
+}
+__device__ __forceinline__ void store_block(char* dst, const BlockRegs& b, int tid) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + c * 256;
+        *reinterpret_cast<u32x4*>(dst + (idx >> 3) * ROW + (idx & 7) * 16) = b.v[c];
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
                                                             long ldo, float* __restrict__ lse, int L, int H, int D,
                                                             int causal, float scale) {
@@ -415,10 +436,15 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __rest
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkb_all = (L + LB - 1) / LB;
     const int nkb = causal ? min(nkb_all, qb + 1) : nkb_all;
+    BlockRegs nk = load_block(base + D, ld, 0, L, tid), nv = load_block(base + 2 * D, ld, 0, L, tid);
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb) __syncthreads();
-        stage_block(sK, base + D, ld, kb * LB, L, tid);
-        stage_block(sV, base + 2 * D, ld, kb * LB, L, tid);
+        store_block(sK, nk, tid);
+        store_block(sV, nv, tid);
+        if (kb + 1 < nkb) {                                   // next block in flight during this block's MFMAs
+            nk = load_block(base + D, ld, (kb + 1) * LB, L, tid);
+            nv = load_block(base + 2 * D, ld, (kb + 1) * LB, L, tid);
+        }
         __syncthreads();
         f32x4 s[4];
         float bm = -INFINITY;
@@ -562,10 +588,15 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkb_all = (L + LB - 1) / LB;
     const int nkb = causal ? min(nkb_all, qb + 1) : nkb_all;
+    BlockRegs nk = load_block(base + D, ld, 0, L, tid), nv = load_block(base + 2 * D, ld, 0, L, tid);
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb) __syncthreads();
-        stage_block(sK, base + D, ld, kb * LB, L, tid);
-        stage_block(sV, base + 2 * D, ld, kb * LB, L, tid);
+        store_block(sK, nk, tid);
+        store_block(sV, nv, tid);
+        if (kb + 1 < nkb) {
+            nk = load_block(base + D, ld, (kb + 1) * LB, L, tid);
+            nv = load_block(base + 2 * D, ld, (kb + 1) * LB, L, tid);
+        }
         __syncthreads();
         f32x4 p[4], ds[4];
         strip_p_ds(sK, sV, q, i, iok, kb * LB, L, causal, scale, li, g, p, ds);
@@ -603,21 +634,24 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
     }
 }
 
-// backward B: dK, dV (and their bias column sums), one workgroup per 64-key block
+// backward B: dK, dV (and their bias column sums), one workgroup per 64-key block, one wave per 16-key tile.
+// Here the scores are formed UN-transposed, S[i][j] = Q K^T with the wave's 16 keys on the accumulator columns
+// (K, V rows of those keys stay in registers for the whole kernel), so P and dS leave the accumulators already in
+// the layout the second products need as B operands (contraction over the queries, in the permuted order the
+// transposed dO^T / Q^T reads match -- the forward kernel's P V trick with keys and queries swapped): no P / dS
+// images in LDS, only the Q and dO blocks (requested one block ahead) and 64 delta / log-sum-exp values.
 __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                                 const bf16_t* __restrict__ o, long ldo,
                                                                 const bf16_t* __restrict__ dout, long lddo,
                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                                 long lddq, float* __restrict__ bias_grad, int L, int H, int D,
                                                                 int causal, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * LB * ROW + 2 * LB * LPROW + 128 * 4];
-    char* sK = smem;
-    char* sV = sK + LB * ROW;
-    char* sQ = sV + LB * ROW;
+    __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW + (2 * LB + 128) * 4];
+    char* sQ = smem;
     char* sDO = sQ + LB * ROW;
-    char* sP = sDO + LB * ROW;
-    char* sDS = sP + LB * LPROW;
-    float* csum = reinterpret_cast<float*>(sDS + LB * LPROW);   // [2][64]: dk | dv
+    float* sLse = reinterpret_cast<float*>(sDO + LB * ROW);
+    float* sDelta = sLse + LB;
+    float* csum = sDelta + LB;                                  // [2][64]: dk | dv
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
@@ -627,9 +661,16 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
     bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
     const float* lse_row = lse + ((long)b * H + h) * L;
     const int li = lane & 15, g = lane >> 4;
+    const int j = kb * LB + wave * 16 + li;                     // this lane's key (accumulator column)
+    const bool jok = j < L;
+    const int jq = min(j, L - 1);
     if (tid < 128) csum[tid] = 0.f;
-    stage_block(sK, base + D, ld, kb * LB, L, tid);
-    stage_block(sV, base + 2 * D, ld, kb * LB, L, tid);
+    bf16x8 kf[2], vf[2];                                        // B operands: K / V rows of key j
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(base + D + (long)jq * ld + ks * 32 + g * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (long)jq * ld + ks * 32 + g * 8);
+    }
     f32x4 av[4], ak[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -637,46 +678,86 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
         ak[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nqb = (L + LB - 1) / LB;
-    for (int qb = causal ? kb : 0; qb < nqb; ++qb) {
-        __syncthreads();                                       // previous block's images / Q / dO consumed (and K, V staged)
-        stage_block(sQ, base, ld, qb * LB, L, tid);
-        stage_block(sDO, dob, lddo, qb * LB, L, tid);
-        {   // P / dS images [query][key] of this (query block, key block) pair: wave = 16-query strip
-            const int i = qb * LB + wave * 16 + li;
-            const bool iok = i < L;
-            const StripOps q = load_strip(base, ld, dob, lddo, ob, ldo, lse_row, min(i, L - 1), g);
-            f32x4 p[4], ds[4];
-            strip_p_ds(sK, sV, q, i, iok, kb * LB, L, causal, scale, li, g, p, ds);
-            const int il = wave * 16 + li;
+    const int qb0 = causal ? kb : 0;
+    const int il = wave * 16 + li;                              // the query this lane serves in the delta pass
+    auto strip_row = [&](int qb) { return min(qb * LB + il, L - 1); };
+    BlockRegs nq = load_block(base, ld, qb0 * LB, L, tid), nd = load_block(dob, lddo, qb0 * LB, L, tid);
+    u32x4 no[2];
+    float nlse;
+    {
+        const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)strip_row(qb0) * ldo + g * 16);
+        no[0] = po[0]; no[1] = po[1];
+        nlse = lse_row[strip_row(qb0)];
+    }
+    for (int qb = qb0; qb < nqb; ++qb) {
+        __syncthreads();                                       // previous block's Q / dO / delta consumed
+        store_block(sQ, nq, tid);
+        store_block(sDO, nd, tid);
+        const u32x4 o0 = no[0], o1 = no[1];
+        const float lse_i = nlse;
+        if (qb + 1 < nqb) {
+            nq = load_block(base, ld, (qb + 1) * LB, L, tid);
+            nd = load_block(dob, lddo, (qb + 1) * LB, L, tid);
+            const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)strip_row(qb + 1) * ldo + g * 16);
+            no[0] = po[0]; no[1] = po[1];
+            nlse = lse_row[strip_row(qb + 1)];
+        }
+        __syncthreads();                                       // Q / dO of this block visible
+        {   // delta_i = sum_c dO[i][c] O[i][c] for the block's 64 queries (4 lanes x 16 columns per query)
+            const u32x4 d0 = *reinterpret_cast<const u32x4*>(sDO + il * ROW + g * 32);
+            const u32x4 d1 = *reinterpret_cast<const u32x4*>(sDO + il * ROW + g * 32 + 16);
+            float dl = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                u32x2 pk = {pack_bf2(p[t][0], p[t][1]), pack_bf2(p[t][2], p[t][3])};
-                u32x2 dk = {pack_bf2(ds[t][0], ds[t][1]), pack_bf2(ds[t][2], ds[t][3])};
-                *reinterpret_cast<u32x2*>(sP + il * LPROW + (t * 16 + g * 4) * 2) = pk;
-                *reinterpret_cast<u32x2*>(sDS + il * LPROW + (t * 16 + g * 4) * 2) = dk;
+            for (int e = 0; e < 4; ++e) {
+                dl += bf_lo(d0[e]) * bf_lo(o0[e]) + bf_hi(d0[e]) * bf_hi(o0[e]);
+                dl += bf_lo(d1[e]) * bf_lo(o1[e]) + bf_hi(d1[e]) * bf_hi(o1[e]);
+            }
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+            if (g == 0) {
+                sDelta[il] = dl;
+                sLse[il] = lse_i;
             }
         }
         __syncthreads();
-        // wave = 16-key tile: dV^T += dO^T P, dK^T += Q^T dS over the block's 64 queries
+        f32x4 p[4], ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                          // S and dP of queries 16 t .. 16 t + 15 against this wave's keys
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                bf16x8 da = *reinterpret_cast<const bf16x8*>(sDO + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp, 0, 0, 0);
+            }
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + t * 16 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + t * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = qb * LB + t * 16 + 4 * g + r;
+                const bool ok = jok && (i < L) && (!causal || j <= i);
+                const float pv = ok ? __expf(sc[r] * scale - l4[r]) : 0.f;
+                p[t][r] = pv;
+                ds[t][r] = pv * (dp[r] - d4[r]) * scale;
+            }
+        }
+        // dV^T += dO^T P, dK^T += Q^T dS: contraction element jj of lane group g <-> query 32 s + 16 (jj>>2) + 4 g + (jj&3)
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
-            const int irow = 32 * sidx + 8 * g + (li >> 2);
-            const char* pcol = sP + irow * LPROW + (wave * 16 + 4 * (li & 3)) * 2;
-            const char* scol = sDS + irow * LPROW + (wave * 16 + 4 * (li & 3)) * 2;
-            bf16x8 pf = tr_pair(pcol, pcol + 4 * LPROW);
-            bf16x8 sf = tr_pair(scol, scol + 4 * LPROW);
-            const int roff = irow * ROW + (4 * (li & 3)) * 2;
+            bf16x8 pf = pack8(p[2 * sidx], p[2 * sidx + 1]);
+            bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
+            const int roff = (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                bf16x8 dof = tr_pair(sDO + roff + ct * 32, sDO + roff + ct * 32 + 4 * ROW);
-                bf16x8 qf = tr_pair(sQ + roff + ct * 32, sQ + roff + ct * 32 + 4 * ROW);
+                bf16x8 dof = tr_pair(sDO + roff + ct * 32, sDO + roff + ct * 32 + 16 * ROW);
+                bf16x8 qf = tr_pair(sQ + roff + ct * 32, sQ + roff + ct * 32 + 16 * ROW);
                 av[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, av[ct], 0, 0, 0);
                 ak[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[ct], 0, 0, 0);
             }
         }
     }
-    const int j = kb * LB + wave * 16 + li;
-    if (j < L) {
+    if (jok) {
         bf16_t* krow = dbase + (long)j * lddq + D + 4 * g;
         bf16_t* vrow = dbase + (long)j * lddq + 2 * D + 4 * g;
 #pragma unroll

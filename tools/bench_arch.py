@@ -40,3 +40,26 @@ dt = (time.perf_counter() - t0) / N
 loss = float(sum(v.detach() for v in ld.values()))
 print(f"{name} B={B}: {dt*1e3:.1f} ms/step = {B/dt:,.0f} pairs/s, loss {loss:.4f}, "
       f"{B/dt*flop_pair/2.5e15*100:.1f} % of bf16 peak on nominal FLOPs")
+
+# per-class breakdown (single stream so that the HIP-event intervals are not stretched by overlap)
+import ctypes
+from clip_event_amd._lib import lib
+cl = lib()
+cl.ce_profile_class_name.restype = ctypes.c_char_p
+model.tower_streams = False
+for _ in range(2):
+    train_step(model, crit, opt, img, txt, yi, yt, ip)
+torch.cuda.synchronize()
+cl.ce_profile_enable(1)
+train_step(model, crit, opt, img, txt, yi, yt, ip)
+torch.cuda.synchronize()
+buf = (ctypes.c_double * (14 * 4))()
+cl.ce_profile_collect(buf, 14)
+cl.ce_profile_enable(0)
+rows = []
+for c in range(14):
+    cnt, ms, fl, by = buf[c * 4:(c + 1) * 4]
+    if cnt > 0:
+        rows.append((ms, cl.ce_profile_class_name(c).decode(), cnt, fl / (ms * 1e-3) / 1e12 if ms else 0, by / (ms * 1e-3) / 1e9 if ms else 0))
+for ms, n, cnt, tf, gb in sorted(rows, reverse=True):
+    print(f"  {n:28s} {cnt:5.0f} launches {ms:8.3f} ms  {tf:7.1f} TF/s {gb:8.1f} GB/s")
