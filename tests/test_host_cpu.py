@@ -160,3 +160,28 @@ def test_checkpoint_layout_round_trip(tmp_path):
         assert v.dtype == torch.float32 and torch.equal(v, sd[k].half().float()), k
     with pytest.raises(FileNotFoundError, match="cannot find checkpoint"):
         C.load_checkpoint(str(tmp_path / "missing.pth"))
+
+
+def test_clip_module_surface(tmp_path):
+    """clip.py:72-166 surface: names, error texts, loading a local state dict / reference-layout checkpoint."""
+    import torch
+    from clip_event_amd import clip
+    assert clip.available_models() == ["RN50", "RN101", "RN50x4", "ViT-B/32"]
+    with pytest.raises(RuntimeError, match="would have to be downloaded"):
+        clip.load("ViT-B/32", device="cpu")
+    with pytest.raises(RuntimeError, match="not found; available models"):
+        clip.load(str(tmp_path / "nope.pt"), device="cpu")
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    sd = O.init_params(cfg, 2)
+    bare = str(tmp_path / "sd.pt")
+    torch.save(sd, bare)
+    with pytest.warns(UserWarning, match="not a JIT archive"):
+        m, pre = clip.load(bare, device="cpu")
+    assert m.visual.input_resolution == 64 and callable(pre)
+    assert all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
+    wrapped = str(tmp_path / "ck.pth")
+    torch.save({"epoch": 1, "model": "t", "state_dict": sd, "perf": 0.0, "optimizer": None}, wrapped)
+    m2, _ = clip.load(wrapped, device="cpu", jit=False)
+    assert all(torch.equal(v, sd[k]) for k, v in m2.state_dict().items())
+    ids = clip.tokenize(["a photo of a cat"])
+    assert ids.shape == (1, 77) and ids[0, :7].tolist() == [49406, 320, 1125, 539, 320, 2368, 49407]

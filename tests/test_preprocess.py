@@ -93,3 +93,17 @@ def test_hip_preprocess_rejects_bad_input():
         preprocess([a.cpu()])
     with pytest.raises(ValueError, match="uint8"):
         preprocess([a.float()])
+
+
+@pytest.mark.gpu
+def test_clip_transform_on_pil_images():
+    """``clip._transform(n_px)`` (the ``preprocess`` returned by ``clip.load``) on PIL images: RGB and greyscale."""
+    from PIL import Image
+    from clip_event_amd import clip
+    pre = clip._transform(224)
+    rgb = _img(500, 375, 3)
+    out = pre(Image.fromarray(rgb)).cpu().numpy()
+    assert np.array_equal(out, _pil_transform(rgb, 224))
+    grey = Image.fromarray(rgb[:, :, 0])                      # mode "L": resize-then-convert == convert-then-resize
+    ref = _pil_transform(np.stack([rgb[:, :, 0]] * 3, axis=-1), 224)
+    assert np.array_equal(pre(grey).cpu().numpy(), ref)
