@@ -4,6 +4,9 @@ global-norm clip to 1 and Adam (fused, optim.py).  With more than one rank the f
 all-gathered for a global-batch InfoNCE and parameter gradients are averaged (distributed.py)."""
 from __future__ import annotations
 
+import logging
+import math
+import sys
 from typing import Dict, Optional
 
 import torch
@@ -31,7 +34,10 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
 
 def train_step(model, criterion, optimizer, image, text, labels_per_image, labels_per_text, index_pos,
                grad_sync: Optional[D.GradSync] = None, criterion_ot: Optional[CriterionAlignment] = None,
-               object_vec=None, entitytxt_vec=None, object_num=None, entitytxt_num=None) -> Dict[str, torch.Tensor]:
+               object_vec=None, entitytxt_vec=None, object_num=None, entitytxt_num=None,
+               check_finite: bool = False) -> Dict[str, torch.Tensor]:
+    """``check_finite`` reproduces engine.py:70-81 (all-rank mean of the losses, ``.item()``, stop on a non-finite
+    value); it costs the host synchronisation the reference pays every step, so it is off by default."""
     optimizer.zero_grad()
     loss_dict = contrastive_step_losses(model, criterion, image, text, labels_per_image, labels_per_text, index_pos)
     passes = 1
@@ -40,6 +46,13 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
         loss_dict.update(criterion_ot(text_features, image_features, entitytxt_num, object_num))
         passes = 2
     losses = sum(loss for loss in loss_dict.values())                                      # engine.py:67
+    if check_finite:
+        reduced = D.reduce_dict({k: v.detach() for k, v in loss_dict.items()})
+        loss_value = float(sum(v for v in reduced.values()))
+        if not math.isfinite(loss_value):
+            logging.error("Loss is {}, stopping training".format(loss_value))
+            logging.error(reduced)
+            sys.exit(1)
     losses.backward()
     if grad_sync is not None:
         grad_sync.finish(passes_per_tower=passes)
