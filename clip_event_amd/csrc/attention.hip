@@ -16,6 +16,8 @@
 // Backward: phase 1 per query strip recomputes P from the saved log-sum-exp, forms
 //   dS = scale * P (dP - delta), writes P^T / dS^T (bf16) to LDS and computes dQ^T = K^T dS^T;
 // phase 2 per 16-key tile computes dV^T = dO^T P and dK^T = Q^T dS from the LDS images.
+#include <mutex>
+
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
@@ -860,12 +862,11 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
     CeProfScope prof(CE_PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (8.0 * D), s);
 #define CALL(TT)                                                                                                   \
     do {                                                                                                           \
-        static bool attr = false;                                                                                  \
-        if (!attr) {                                                                                               \
+        static std::once_flag attr;                                                                                \
+        std::call_once(attr, [] {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<TT>),                                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
-            attr = true;                                                                                           \
-        }                                                                                                          \
+        });                                                                                                        \
         hipLaunchKernelGGL(attn_bwd_kernel<TT>, dim3(B * H), dim3(64 * nw), lds, s, (const bf16_t*)qkv, ld,        \
                            (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, cu_seqlens, L, \
                            H, D, causal, scale);                                                                           \

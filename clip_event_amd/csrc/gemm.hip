@@ -23,6 +23,8 @@
 // global_atomic_add_f32.  The M range is split across workgroups to fill the chip.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
@@ -1052,20 +1054,19 @@ inline long nt32_cost(long tiles) {
 
 template <int EPI, int TM>
 void launch_nt256(NTArgs& a, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;       // forward runs on the caller's thread, backward on autograd's
+    std::call_once(attr, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, TM, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
-        attr = true;
-    }
+    });
     a.tiles_m = ce_div_up(a.M, 32 * TM);
     hipLaunchKernelGGL((gemm_nt256_kernel<EPI, TM, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
 }
 
 template <int EPI>
 int launch_nt(NTArgs a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, 5, 2>),
@@ -1074,8 +1075,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
-        attr_set = true;
-    }
+    });
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
     CeProfScope prof(CE_PROF_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
     const int force = nt_variant();
@@ -1190,17 +1190,16 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
                                   const long* ldq, int M, const int* Nn, const int* Kk, float* const* out,
                                   const long* ldo, int splits, void* stream) {
     CE_CHECK_ARG(count >= 1 && count <= 4 && M > 0, "ce_gemm_tn_grouped: 1..4 problems, M > 0");
-    static bool attr_set = false;
+    static std::once_flag attr_set;
     static int variant = 2;   // CE_GEMM_TN=1 forces the register-staged v1 kernel (one launch per problem)
-    if (!attr_set) {
+    std::call_once(attr_set, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TN_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             T2_LDS_BYTES);
         const char* e = getenv("CE_GEMM_TN");
         if (e) variant = atoi(e);
-        attr_set = true;
-    }
+    });
     hipStream_t s = (hipStream_t)stream;
     TNGroup g;
     g.count = count;
