@@ -130,8 +130,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("CE_ALL_RANKS_ON_GPU0"):      # rehearsal of the N>1 path on a one-GPU box
         local_rank = 0
-    if W > 1:
+    force = os.environ.get("CE_FORCE_COLLECTIVES", "0") == "1"    # one rank, but through every RCCL call
+    if W > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                          # single-rank rehearsal: any free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         backend = os.environ.get("CE_DIST_BACKEND", "nccl")          # "nccl" == RCCL on ROCm; gloo only to rehearse
         if backend == "nccl":                                        # several ranks on a one-GPU box
@@ -156,7 +164,7 @@ def main():
         lib().ce_tower_wgrad_stream(0)
     crit = CriterionContrastive("ce")
     opt = FusedAdam(model, lr=1e-6, weight_decay=0.0, max_norm=1.0)    # README.md:189-191 defaults
-    sync = D.GradSync(model) if W > 1 else None
+    sync = D.GradSync(model) if ((W > 1 or force) and os.environ.get("CE_NO_GRAD_SYNC", "0") != "1") else None
     img = S.synthetic_images(B, 224, seed=999 + rank).to(dev)
     K = max(1, args.descriptions)
     txt = S.synthetic_tokens(B * K, 77, 49408, seed=999 + rank).to(dev)
@@ -283,7 +291,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if W > 1:
+    if W > 1 or force:
         dist.destroy_process_group()
 
 

@@ -17,14 +17,26 @@ Everything here is device-agnostic (the CPU tests run it on gloo with world_size
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
 
 
+# Rehearsal switch: with one rank, still issue every collective of the data-parallel path (they are identities at
+# world size 1).  Lets the exact multi-GPU code path -- RCCL calls from the towers' side streams and from autograd's
+# thread, gradient pieces, pending handles -- run on a one-GPU box (bench.py with CE_FORCE_COLLECTIVES=1).
+FORCE_COLLECTIVES = os.environ.get("CE_FORCE_COLLECTIVES", "0") == "1"
+
+
 def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized()
+
+
+def active() -> bool:
+    """True when the step must go through the collectives: more than one rank, or the rehearsal switch."""
+    return is_dist() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def world_size() -> int:
@@ -63,7 +75,7 @@ class _AllGatherFn(torch.autograd.Function):
 
 def gather_features(x: torch.Tensor) -> torch.Tensor:
     """[n, E] on every rank -> [W*n, E] in rank order; gradient flows back to every owner."""
-    if world_size() == 1:
+    if not active():
         return x
     return _AllGatherFn.apply(x)
 
@@ -72,9 +84,9 @@ def gather_feature_pair(fi: torch.Tensor, ft: torch.Tensor):
     """Both feature matrices of a step in ONE all-gather (and one reduce-scatter in the backward): the exchange is
     latency-bound (a few hundred KB per rank), so two collectives cost twice one.  ``fi`` [B, E], ``ft`` [B*K, E] ->
     ``(fi_all [W*B, E], ft_all [W*B*K, E])`` in rank order."""
-    W = world_size()
-    if W == 1:
+    if not active():
         return fi, ft
+    W = world_size()
     B, n = fi.shape[0], ft.shape[0]
     both = gather_features(torch.cat([fi, ft], dim=0)).view(W, B + n, fi.shape[1])
     return both[:, :B].reshape(W * B, -1), both[:, B:].reshape(W * n, -1)
@@ -125,8 +137,10 @@ class GradSync:
     optimiser runs.  xGMI is point-to-point, so a ring all-reduce of the 600 MB buffer costs milliseconds: only
     the last piece (lowest blocks + input embeddings of the tower that finishes last) stays exposed."""
 
-    def __init__(self, model, pieces_per_tower: int = 3):
+    def __init__(self, model, pieces_per_tower: Optional[int] = None):
         self.model = model
+        if pieces_per_tower is None:
+            pieces_per_tower = int(os.environ.get("CE_GRAD_PIECES", "3"))
         self.pieces = max(1, int(pieces_per_tower))
         self.pending = []
         self.done = set()
@@ -135,7 +149,7 @@ class GradSync:
 
     def layer_cuts(self, tower: str, layers: int):
         """Blocks at which a tower's backward pauses to hand over gradients: ``pieces`` roughly equal groups."""
-        if world_size() < 2 or self.pieces < 2 or tower in self.done:
+        if not active() or self.pieces < 2 or tower in self.done:
             return []
         cuts = sorted({(layers * k) // self.pieces for k in range(1, self.pieces)}, reverse=True)
         return [c for c in cuts if 0 < c < layers]
@@ -158,7 +172,7 @@ class GradSync:
         self._reduce_range(a, b, async_op)
 
     def _on_tower(self, model, name: str, upto_layer: Optional[int] = None):
-        if world_size() < 2 or name in self.done:
+        if not active() or name in self.done:
             return
         # a tower that runs several passes per step (sim_entity, region branch) is reduced again at finish()
         a, b = model._ranges[name]
@@ -172,7 +186,7 @@ class GradSync:
     __call__ = _on_tower
 
     def finish(self, passes_per_tower: int = 1):
-        if world_size() < 2:
+        if not active():
             return
         if passes_per_tower > 1:
             for h in self.pending:

@@ -20,7 +20,7 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
                             index_pos, global_batch: bool = True) -> Dict[str, torch.Tensor]:
     """Forward + criterion.  ``global_batch`` (W > 1): logits_per_image = s * I_local @ T_all^T,
     logits_per_text = s * T_local @ I_all^T with labels from ``distributed.global_labels``."""
-    if D.world_size() > 1 and global_batch:
+    if D.active() and global_batch:
         fi, ft = model.encode_both(image, text)
         fi_all, ft_all = D.gather_feature_pair(fi, ft)
         overbatch = model.constrastive_overbatch
