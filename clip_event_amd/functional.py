@@ -359,7 +359,10 @@ class LogitsFn(torch.autograd.Function):
             lpi = _empty((B, K), torch.float32, dev)
             check(cl.ce_instance_logits(ptr(In), ptr(Tn), ptr(ls), ptr(lpi), c_int(B), c_int(K), c_int(E), s),
                   "ce_instance_logits")
-        ctx.saved = (In, Tn, inv_i, inv_t, ls, lpi, lpt)
+        # the logits are this node's OUTPUTS: keeping the tensors themselves on ctx would close a cycle through their
+        # grad_fn (= ctx) that Python's collector cannot see, and every step's whole graph (both towers' activation
+        # stashes) would stay alive; detached aliases share the storage without the back edge
+        ctx.saved = (In, Tn, inv_i, inv_t, ls, None if lpi is None else lpi.detach(), None if lpt is None else lpt.detach())
         ctx.overbatch = overbatch
         return lpi, lpt
 
