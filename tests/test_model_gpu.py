@@ -341,6 +341,43 @@ def test_no_graph_is_kept_alive_between_steps():
     assert max(sizes[3:]) - min(sizes[3:]) < 2 * 2**20, "device memory grows from step to step"
 
 
+def test_no_graph_is_kept_alive_in_the_other_branches():
+    """Same check for the per-instance logits, the train_arg region branch and sim_entity + OT alignment."""
+    import gc
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionAlignment, CriterionContrastive
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    m, _ = _mk(cfg, 3)
+    B, K = 4, 3
+    img = S.synthetic_images(B, cfg.image_resolution, seed=1).to(DEV)
+    txt = S.synthetic_tokens(B * K, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
+    yi, yt, ip = (t.to(DEV) for t in O.build_labels(B, 1, K - 1, False))
+    crit, crit_ot = CriterionContrastive("ce"), CriterionAlignment()
+    bboxs = S.synthetic_bboxes(B, seed=5)
+    desc = [S.synthetic_tokens(len(b), cfg.context_length, cfg.vocab_size, seed=50 + i, min_len=2).to(DEV) for i, b in enumerate(bboxs)]
+    obj = torch.randn(B, 3, 3, cfg.image_resolution, cfg.image_resolution, device=DEV)
+    ent = S.synthetic_tokens(B * 4, cfg.context_length, cfg.vocab_size, seed=9, min_len=2).view(B, 4, -1).to(DEV)
+    on = torch.ones(B, 3, dtype=torch.long, device=DEV)
+    en = torch.ones(B, 4, dtype=torch.long, device=DEV)
+    sizes = []
+    for it in range(8):
+        m.zero_grad(set_to_none=True)
+        m.set_hyps(constrastive_overbatch=False, alignment=True)
+        li, lt, lb, la = m(img, txt[:B], train_arg="desc", bboxs=bboxs, bbox_desc_vec=desc, bbox_label_vec=desc)
+        lpi, lpt = m(img, txt)                                   # per-instance logits [B, K]
+        ld = crit(lpi, lpt, yi, yt, index_pos=ip, constrastive_overbatch=False)
+        fi, ft = m.sim_entity(obj, ent)
+        ld.update(crit_ot(ft, fi, en, on))
+        (sum(ld.values()) + lb + la).backward()
+        del li, lt, lb, la, lpi, lpt, ld, fi, ft
+        torch.cuda.synchronize()
+        gc.collect()
+        sizes.append(torch.cuda.memory_allocated())
+    print("allocated MiB per step:", [round(s / 2**20, 2) for s in sizes])
+    assert max(sizes[2:]) - min(sizes[2:]) < 2 * 2**20, "device memory grows from step to step"
+
+
 def test_ot_alignment_against_reference_golden():
     """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
     recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""
