@@ -78,6 +78,31 @@ def test_full_size_step_packed_equals_dense(vitb32):
             assert _rel(g_p[a:b], g_d[a:b]) < 3e-3, (name, _rel(g_p[a:b], g_d[a:b]))
 
 
+def test_full_size_step_is_reproducible(vitb32):
+    """Two streams, side-stream gradient writes, lazy and eager gradient zeroing: repeated identical steps must agree
+    up to the order of the fp32 atomic adds (1e-6), whichever zero_grad flavour precedes them.  A cross-stream race
+    shows up here as a per-step difference of several per cent."""
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    m = vitb32
+    B = 256
+    img = S.synthetic_images(B, 224, seed=7).to(DEV)
+    txt = S.synthetic_tokens(B, 77, 49408, seed=7).to(DEV)
+    y = torch.arange(B, device=DEV)
+    crit = CriterionContrastive("ce")
+
+    def run(set_none):
+        m.zero_grad(set_to_none=set_none)
+        ld = crit(*m(img, txt), y, y, index_pos=y)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        return m._flat_grad.detach().clone()
+
+    ref = run(True)
+    for it in range(6):
+        assert _rel(run(it % 2 == 0), ref) < 1e-6
+
+
 def test_full_size_hard_negative_rows(vitb32):
     """Config c3's shape on one GPU at reduced batch (B = 64 images x K = 5 descriptions = 320 captions): the logits of
     the full [B, B*K] problem restricted to a sub-batch equal the sub-batch run alone (rows are independent), and the
