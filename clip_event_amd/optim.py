@@ -27,6 +27,10 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, model, lr: float = 1e-6, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  max_norm=1.0):
+        frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+        if frozen:
+            raise NotImplementedError("FusedAdam updates the whole flat parameter buffer; frozen parameters "
+                                      f"({frozen[:3]}...) need torch.optim.Adam over the trainable ones instead")
         self.model = model
         self.max_norm = max_norm
         self.step_count = 0
