@@ -89,8 +89,14 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
     for (int r = blockIdx.x * 16 + wave; r < M; r += gridDim.x * 16) {
         const long dst = rows ? (long)rows[r] : (long)r;
         const float mu = mean[r], rs = rstd[r];
-        f32x4 xh[IT], gy[IT];
+        f32x4 xh[IT], gy[IT], din[IT];
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {      // every load of the row is issued before the reductions (one memory latency per row)
+            const int c = i * 256 + lane * 4;
+            din[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < D && dx_in) din[i] = *reinterpret_cast<const f32x4*>(dx_in + dst * lddx + c);
+        }
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = i * 256 + lane * 4;
@@ -120,8 +126,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
         for (int i = 0; i < IT; ++i) {
             const int c = i * 256 + lane * 4;
             if (c < D) {
-                f32x4 o = (gy[i] - c1 - xh[i] * c2) * rs;
-                if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + dst * lddx + c);
+                f32x4 o = (gy[i] - c1 - xh[i] * c2) * rs + din[i];
                 *reinterpret_cast<f32x4*>(dx_out + dst * lddx + c) = o;
                 ax[i] += o;
                 if (dxb) {
