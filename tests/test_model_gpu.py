@@ -421,6 +421,31 @@ def test_stock_torch_optimizer_path_matches_fused():
     assert _rel(db, da) < 2e-2 and worst_cos > 0.995
 
 
+def test_load_state_dict_into_a_prepared_model():
+    """Parameters are views of one flat buffer and the GEMMs read bf16 copies of them: loading other weights into a
+    model that has already run (in-place copies into the views) must refresh every operand copy."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    m, _ = _mk(cfg, 1)
+    img = S.synthetic_images(3, cfg.image_resolution, seed=1).to(DEV)
+    txt = S.synthetic_tokens(3, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
+    with torch.no_grad():
+        before = [t.clone() for t in m(img, txt)]
+    other = O.init_params(cfg, 2)
+    m.load_state_dict({k: v.clone() for k, v in other.items()})
+    fresh, _ = _mk(cfg, 2)
+    with torch.no_grad():
+        got, ref = m(img, txt), fresh(img, txt)
+    assert not torch.allclose(got[0], before[0])
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    # and gradients flow into the same flat buffer afterwards
+    li, lt = m(img, txt)
+    (li.sum() + lt.sum()).backward()
+    assert all(p.grad is not None and p.grad.data_ptr() == m._flat_grad.data_ptr() + m._offsets[n] * 4
+               for n, p in m.named_parameters())
+
+
 def test_ot_alignment_against_reference_golden():
     """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
     recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""
