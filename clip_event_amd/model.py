@@ -208,6 +208,30 @@ class CLIP(nn.Module):
         # are unchanged, see functional.text_packing.  CE_TEXT_PACK=0 keeps the dense [n, 77] layout.
         self.pack_text = os.environ.get("CE_TEXT_PACK", "1") != "0"
 
+    # ---- copy / pickle: the device-side tables (ctypes descriptors, workspace pool, streams, operand copies) are
+    # rebuilt lazily by _prepare(); only the parameters and the plain attributes travel --------------------------
+    _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
+                "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
+                "_tjobs_n", "_tjobs_tiles", "_mirror_fresh", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
+                "_side_streams", "_main_stream", "_pack_cache", "grad_sync")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._RUNTIME:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._flat = None
+        self._flat_grad = None
+        self._pool = _Pool()
+        self._trigger = None
+        self._versions = None
+        self.grad_sync = None
+        for p in self.parameters():            # parameters arrive as copies of the views: gradients start afresh
+            p.grad = None
+
     # ---- reference API -------------------------------------------------------------------
     def set_hyps(self, constrastive_overbatch=True, alignment=False, multiattention=False):
         self.constrastive_overbatch = constrastive_overbatch

@@ -446,6 +446,39 @@ def test_load_state_dict_into_a_prepared_model():
                for n, p in m.named_parameters())
 
 
+def test_gradients_accumulate_across_backward_calls():
+    """Two backward passes without zero_grad in between add up (every kernel accumulates into the flat buffer)."""
+    import copy
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    cfg = O.ClipConfig(64, 64, 2, 128, 32, 20, 512, 128, 2, 2)
+    m, _ = _mk(cfg, 4)
+    img = S.synthetic_images(5, cfg.image_resolution, seed=1).to(DEV)
+    txt = S.synthetic_tokens(5, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
+    yi, yt, ip = (t.to(DEV) for t in O.build_labels(5, 1, 0, True))
+    crit = CriterionContrastive("ce")
+
+    def backward_once():
+        ld = crit(*m(img, txt), yi, yt, index_pos=ip)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+
+    m.zero_grad()
+    backward_once()
+    g1 = m._flat_grad.clone()
+    backward_once()
+    assert _rel(m._flat_grad, 2 * g1) < 1e-5
+    # a deep copy is an independent model with its own flat buffers
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        a, b = m(img, txt)[0], m2(img, txt)[0]
+    assert torch.equal(a, b) and m2._flat.data_ptr() != m._flat.data_ptr()
+    with torch.no_grad():
+        m2.logit_scale.fill_(0.5)
+    assert float(m.logit_scale) != 0.5
+
+
 def test_ot_alignment_against_reference_golden():
     """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
     recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""
