@@ -498,6 +498,11 @@ class CLIP(nn.Module):
     def _ready(self):
         if not self._flat_ok():
             self._prepare()
+        dev = self._flat.device
+        if torch.cuda.current_device() != dev.index:
+            # launches go to the CURRENT device's stream: running a model that lives on another GPU would fault
+            raise RuntimeError(f"the model lives on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                               "call torch.cuda.set_device() first (one process per GPU)")
         self.refresh_operands()
 
     # ---- encoders -------------------------------------------------------------------------
