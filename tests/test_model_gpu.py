@@ -479,6 +479,56 @@ def test_gradients_accumulate_across_backward_calls():
     assert float(m.logit_scale) != 0.5
 
 
+def test_tower_backward_in_layer_ranges_equals_one_call():
+    """The data-parallel exchange cuts each tower's backward into layer ranges (ce_tower_backward_range) and is
+    notified after each: same gradients as the single call, notifications top-down, and at each notification the
+    handed-over prefix of the tower's gradient range is already final."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    cfg = O.ClipConfig(64, 64, 5, 128, 32, 20, 512, 128, 2, 4)
+    m, _ = _mk(cfg, 6)
+    img = S.synthetic_images(4, cfg.image_resolution, seed=1).to(DEV)
+    txt = S.synthetic_tokens(4, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
+    yi, yt, ip = (t.to(DEV) for t in O.build_labels(4, 1, 0, True))
+    crit = CriterionContrastive("ce")
+
+    def backward():
+        m.zero_grad()
+        ld = crit(*m(img, txt), yi, yt, index_pos=ip)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        return m._flat_grad.clone()
+
+    ref = backward()
+
+    class Recorder:
+        def __init__(self):
+            self.calls, self.snap = [], {}
+
+        def layer_cuts(self, tower, layers):
+            return [c for c in (layers - 1, layers // 2, 1) if 0 < c < layers]
+
+        def __call__(self, model, tower, upto_layer=None):
+            self.calls.append((tower, upto_layer))
+            torch.cuda.current_stream().synchronize()
+            a, b = model._ranges[tower]
+            end = b if upto_layer is None else model._layer_end[tower][upto_layer]
+            self.snap[(tower, upto_layer)] = (a, end, model._flat_grad[a:end].clone())
+
+    rec = Recorder()
+    m.grad_sync = rec
+    got = backward()
+    m.grad_sync = None
+    assert _rel(got, ref) < 1e-6
+    for tower, layers in (("visual", 5), ("text", 4)):
+        seq = [u for t_, u in rec.calls if t_ == tower]
+        assert seq == [c for c in (layers - 1, layers // 2, 1) if 0 < c < layers] + [None], seq
+        for key, (a, end, snap) in rec.snap.items():
+            if key[0] == tower:       # what was handed over at that moment is what the finished backward holds
+                assert _rel(snap, ref[a:end]) < 1e-6, key
+
+
 def test_ot_alignment_against_reference_golden():
     """CriterionAlignment / IPOT on the HIP kernel vs the imported reference (fp32 both; the IPOT
     recurrence amplifies summation-order differences over 50 iterations: 1e-4 relative)."""
