@@ -95,14 +95,14 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4
 // 8*wm + row-phase), then thread c adds column c's 16 entries and issues the workgroup's ONE global atomic for
 // that column: 4 atomic wave-instructions per workgroup instead of 64, no cross-lane shuffles.
 __device__ __forceinline__ void wg_colsum_flush(char* smem, float* __restrict__ colsum, int n0, int N, int n_local,
-                                                int srow, const f32x4& cs0, const f32x4& cs1) {
+                                                int srow, const f32x4& cs0, const f32x4& cs1, int bn = 256) {
     constexpr int SROW = 264;                              // floats: 256 + 8 pad (rows shift by 8 banks)
     float* strip = reinterpret_cast<float*>(smem);
     __syncthreads();                                       // every wave is done with its epilogue slice
     *reinterpret_cast<f32x4*>(strip + srow * SROW + n_local) = cs0;
     *reinterpret_cast<f32x4*>(strip + srow * SROW + n_local + 4) = cs1;
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    for (int i = threadIdx.x; i < bn; i += blockDim.x) {      // bn = columns of the workgroup's tile
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += strip[r * SROW + i];
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
         }
     }
     if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
-        if (p.out2) wg_colsum_flush(smem, reinterpret_cast<float*>(p.out2), n0, p.N, gn - n0, wm * 8 + e_r, cs0, cs1);   // block-uniform
+        if (p.out2) wg_colsum_flush(smem, reinterpret_cast<float*>(p.out2), n0, p.N, gn - n0, wm * 8 + e_r, cs0, cs1, N2_BN);   // block-uniform
     }
 }
 
@@ -1053,6 +1053,17 @@ inline long nt32_cost(long tiles) {
 }
 
 template <int EPI, int TM>
+void launch_nt128(NTArgs& a, hipStream_t stream) {      // (32 TM) x 128 tile, 4 waves, two workgroups per CU
+    static std::once_flag attr;
+    std::call_once(attr, [] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<EPI, TM, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N2H_LDS_BYTES);
+    });
+    a.tiles_m = ce_div_up(a.M, 32 * TM);
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, TM, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), N2H_LDS_BYTES, stream, a);
+}
+
+template <int EPI, int TM>
 void launch_nt256(NTArgs& a, hipStream_t stream) {
     static std::once_flag attr;       // forward runs on the caller's thread, backward on autograd's
     std::call_once(attr, [] {
@@ -1097,7 +1108,31 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             }
         }
         const bool use32 = f == 32 || (f == 0 && a.K % N3_BK == 0 && nt32_cost(t5) < best_cost);
-        if (use32) {
+        // Where the cost model picks a 256-column tile with one workgroup per CU, use the 160 x 128 four-wave tile
+        // instead (72 KiB LDS: two workgroups per CU): alone it is no faster, but with the two towers on two streams a
+        // workgroup of the OTHER tower's GEMM can share the CU and fill this one's prologue / epilogue (0.5-2 % on
+        // the step, box dependent).  CE_NT_POLICY: bit 0 = that (default), bit 1 = also instead of the two-workgroup
+        // 160x256x32 kernel (slower), bit 2 = pick the tile height 96..160 by rounds over the 512 slots (slower).
+        static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 1;
+        const bool half = f == 104 || (f >= 203 && f <= 205) || (f == 0 && ((policy & 1) && !use32 || (policy & 2) && use32));
+        if (half) {
+            a.tiles_n = ce_div_up(a.N, 128);
+            int htm = 5;
+            if (f >= 203 && f <= 205) htm = f - 200;
+            else if (f == 0 && (policy & 4)) {        // tile height by rounds over the 512 slots
+                long bc = -1;
+                for (int tm = 5; tm >= 3; --tm) {
+                    const long tiles = (long)ce_div_up(a.M, 32 * tm) * a.tiles_n;
+                    const long cost = ((tiles + 511) / 512) * (28 + 10 * tm);
+                    if (bc < 0 || cost < bc) { bc = cost; htm = tm; }
+                }
+            }
+            switch (htm) {
+                case 3: launch_nt128<EPI, 3>(a, stream); break;
+                case 4: launch_nt128<EPI, 4>(a, stream); break;
+                default: launch_nt128<EPI, 5>(a, stream); break;
+            }
+        } else if (use32) {
             a.tiles_m = ce_div_up(a.M, N3_BM);
             hipLaunchKernelGGL(gemm_nt32_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), N3_LDS_BYTES, stream, a);
         } else if (f == 104) {   // 160x128, two workgroups per CU: measured equal to the 8-wave 160x256 tile, kept as an option
