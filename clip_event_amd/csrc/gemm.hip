@@ -1111,10 +1111,13 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         // Where the cost model picks a 256-column tile with one workgroup per CU, use the 160 x 128 four-wave tile
         // instead (72 KiB LDS: two workgroups per CU): alone it is no faster, but with the two towers on two streams a
         // workgroup of the OTHER tower's GEMM can share the CU and fill this one's prologue / epilogue (0.5-2 % on
-        // the step, box dependent).  CE_NT_POLICY: bit 0 = that (default), bit 1 = also instead of the two-workgroup
-        // 160x256x32 kernel (slower), bit 2 = pick the tile height 96..160 by rounds over the 512 slots (slower).
+        // the step, box dependent), when its tiles fit one resident round (512 slots).  CE_NT_POLICY: bit 0 = that
+        // (default), bit 1 = also instead of the two-workgroup 160x256x32 kernel (slower), bit 2 = pick the tile height
+        // 96..160 by rounds over the 512 slots (slower in the step), bit 3 = also for multi-round launches (noise).
         static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 1;
-        const bool half = f == 104 || (f >= 203 && f <= 205) || (f == 0 && ((policy & 1) && !use32 || (policy & 2) && use32));
+        const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
+        const bool half = f == 104 || (f >= 203 && f <= 205) ||
+                          (f == 0 && (half_tiles <= 512 || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
         if (half) {
             a.tiles_n = ce_div_up(a.N, 128);
             int htm = 5;
