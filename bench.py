@@ -47,8 +47,15 @@ def parse():
                     help="run the text tower on all 77 positions of every caption (default: live tokens SOT..EOT only; "
                          "the default run also reports this dense variant as config.dense_text)")
     ap.add_argument("--no-dense-compare", action="store_true", help="skip the dense-text comparison run")
-    ap.add_argument("--fresh-captions", action="store_true",
-                    help="hand the model a NEW caption tensor every step (forces the per-batch length read-back)")
+    ap.add_argument("--reuse-captions", action="store_true",
+                    help="hand the model the SAME caption tensor every step (its live-token layout is then cached; the "
+                         "default gives every step a new tensor, so the per-batch length read-back of real training is "
+                         "inside the timed region)")
+    ap.add_argument("--alignment", action="store_true",
+                    help="BASELINE config 4: add sim_entity + the IPOT alignment loss (object crops / entity mentions "
+                         "as SURVEY 8(d) c4: 1+U[0,6] objects, U[1,10] entities per image)")
+    ap.add_argument("--train-arg", default=None, choices=["desc", "desc_type", "desc_type_text"],
+                    help="BASELINE config 4: add the region / argument branch (U[1,4] roles per image, 25%% None boxes)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run both towers on one stream (the default overlaps them on two)")
     return ap.parse_args()
@@ -107,7 +114,14 @@ def pmc_traffic(kernel_class):
     + WRITE_SIZE, tools/pmc_traffic.py; PMC needs its own runs, so bench.py cannot collect it live)."""
     import glob
     prefix = {"gemm_tn": "gemm_tn2_kernel"}.get(kernel_class)
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic*.json")))
+    import re
+
+    def version_key(path):          # r02_..._v10.json sorts after r02_..._v9.json, and r02 after r01
+        nums = [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
+        return (nums, os.path.getmtime(path))
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic*.json")),
+                   key=version_key)
     if not prefix or not files:
         return None, None
     try:
@@ -117,6 +131,21 @@ def pmc_traffic(kernel_class):
     except Exception:
         pass
     return None, None
+
+
+def mfma_util():
+    """MFMA utilisation per kernel class from the committed rocprofv3 PMC pass (SQ_VALU_MFMA_BUSY_CYCLES /
+    SQ_BUSY_CU_CYCLES, tools/pmc_mfma.py); PMC needs its own run, so bench.py reads the summary."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_util*.json")),
+                   key=lambda f: ([int(x) for x in re.findall(r"\d+", os.path.basename(f))], os.path.getmtime(f)))
+    if not files:
+        return None
+    try:
+        return {"source": os.path.basename(files[-1]), "kernels": json.load(open(files[-1]))[:8]}
+    except Exception:
+        return None
 
 
 def ms_per_step_tmp(dt, steps):
@@ -169,13 +198,26 @@ def main():
     K = max(1, args.descriptions)
     txt = S.synthetic_tokens(B * K, 77, 49408, seed=999 + rank).to(dev)
     yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=dev, rank_=rank)
+    extra = {}
+    if args.alignment:
+        from clip_event_amd.losses import CriterionAlignment
+        model.set_hyps(True, True, False)
+        obj, obj_num, ent, ent_num = S.synthetic_entities(B, 224, 77, 49408, seed=1999 + rank)
+        extra.update(criterion_ot=CriterionAlignment(), object_vec=obj.to(dev), entitytxt_vec=ent.to(dev),
+                     object_num=obj_num.to(dev), entitytxt_num=ent_num.to(dev))
+        log(f"alignment: object_vec {tuple(obj.shape)}, entitytxt_vec {tuple(ent.shape)}")
+    if args.train_arg:
+        boxes = S.synthetic_bboxes(B, seed=2999 + rank)
+        extra.update(train_arg=args.train_arg, bboxs=boxes,
+                     bbox_desc_vec=[t.to(dev) for t in S.synthetic_role_texts(boxes, seed=3999 + rank)],
+                     bbox_label_vec=[t.to(dev) for t in S.synthetic_role_texts(boxes, seed=4999 + rank)])
 
     if args.dense_text:
         model.pack_text = False
 
     def step():
-        t = txt.clone() if args.fresh_captions else txt
-        return train_step(model, crit, opt, img, t, yi, yt, ip, grad_sync=sync)
+        t = txt if args.reuse_captions else txt.clone()
+        return train_step(model, crit, opt, img, t, yi, yt, ip, grad_sync=sync, **extra)
 
     def timed(nsteps):
         if W > 1:
@@ -205,7 +247,7 @@ def main():
     lens = (txt.argmax(dim=-1) + 1).sum().item()
     live_frac = 1.0 if args.dense_text else lens / float(B * K * 77)
     dense = None
-    if not args.dense_text and not args.no_dense_compare:      # the same step with every caption padded out to 77 rows, for comparison
+    if not args.dense_text and not args.no_dense_compare and not extra:      # the same step with every caption padded out to 77 rows, for comparison
         model.pack_text = False
         nd = max(5, args.steps // 2)
         for _ in range(2):
@@ -259,12 +301,16 @@ def main():
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(top["gbps"] * 1e9 * top["avg_us"] * 1e-6),
                 "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
-                # nominal = SURVEY 8(d)'s 44.10 GFLOP/pair (all 77 text positions); executed = FLOPs actually issued
-                # (text-tower GEMM work scales with the live-row fraction)
-                "step_frac_of_bf16_peak": round(pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR) / PEAK_BF16, 4),
-                "step_frac_of_bf16_peak_executed": round(
+                # step_frac = the FLOPs the step actually ISSUES (text-tower GEMM work scales with the live-row
+                # fraction of the packed layout) / time / peak: the figure to hold against the 40 % target.  The
+                # nominal figure prices every pair at SURVEY 8(d)'s 44.10 GFLOP (all 77 text positions) and is
+                # kept only for comparison with dense-text implementations.
+                "step_frac": round(
                     pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR
                                        - K * TEXT_FLOP_PER_PAIR * (1.0 - live_frac)) / PEAK_BF16, 4),
+                "step_frac_nominal_44_10_gflop_per_pair": round(
+                    pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR) / PEAK_BF16, 4),
+                "mfma_utilisation": mfma_util(),
                 "classes": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
     if W > 1:
         dist.barrier()
@@ -286,7 +332,8 @@ def main():
                        "text_rows": ("all 77 positions" if args.dense_text else
                                      "live tokens SOT..EOT only: %.1f%% of B*77 rows (identical results, see DESIGN.md)"
                                      % (100.0 * live_frac)),
-                       "fresh_captions_every_step": bool(args.fresh_captions),
+                       "fresh_captions_every_step": not args.reuse_captions,
+                       "alignment": bool(args.alignment), "train_arg": args.train_arg,
                        "dense_text": dense},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -323,8 +323,11 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[q ^ 1], w, p.g_ln1_w,
                              p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
     }
-    wait_done(0);
-    wait_done(1);
+    // every weight-gradient launch of this call that the loop has not already waited for (block l's is waited for
+    // by block l-1's ln_1 backward): the two lowest blocks of the range.  The caller hands the gradients of
+    // blocks >= layer_lo to the all-reduce as soon as this returns.
+    wait_done(layer_lo);
+    wait_done(layer_lo + 1);
     return 0;
 }
 

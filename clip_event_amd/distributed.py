@@ -30,21 +30,41 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = os.environ.get("CE_FORCE_COLLECTIVES", "0") == "1"
 
 
+_LOCAL_ONLY = 0          # depth of `local_only()` contexts in this process
+
+
 def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+class local_only:
+    """Context manager: inside it this process computes as if no process group existed (``active()`` is False,
+    ``world_size()`` 1, ``rank()`` 0, no collective is issued).  For single-process reference runs inside a
+    multi-rank job -- e.g. rank 0 recomputing the concatenated batch in the W>1 parity tests -- and for strict
+    reference-DDP equivalence of the loss (local InfoNCE)."""
+
+    def __enter__(self):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY -= 1
+        return False
+
+
 def active() -> bool:
     """True when the step must go through the collectives: more than one rank, or the rehearsal switch."""
-    return is_dist() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+    return _LOCAL_ONLY == 0 and is_dist() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def world_size() -> int:
-    return dist.get_world_size() if is_dist() else 1
+    return dist.get_world_size() if (is_dist() and _LOCAL_ONLY == 0) else 1
 
 
 def rank() -> int:
-    return dist.get_rank() if is_dist() else 0
+    return dist.get_rank() if (is_dist() and _LOCAL_ONLY == 0) else 0
 
 
 class _AllGatherFn(torch.autograd.Function):
@@ -127,29 +147,60 @@ def reduce_dict(input_dict: Dict[str, torch.Tensor], average: bool = True) -> Di
 
 class GradSync:
     """Mean all-reduce of the flat gradient buffer, bucketed per tower and, inside a tower, per group of
-    residual blocks.
+    residual blocks -- the drop-in's counterpart of ``DistributedDataParallel``'s reducer (train.py:222-225).
 
     ``model.grad_sync`` is called by each tower's backward: after every layer range (``upto_layer``: the blocks
     down to that one are final; their gradients are a contiguous prefix of the tower's range, model._prepare) and
     once more when the whole tower, embeddings included, has been enqueued.  Each piece's all-reduce is issued
-    asynchronously (RCCL runs it on its own stream, ordered after the launches enqueued so far) and overlaps the
-    rest of the backward.  ``finish()`` reduces what is left (logit_scale) and waits for everything before the
-    optimiser runs.  xGMI is point-to-point, so a ring all-reduce of the 600 MB buffer costs milliseconds: only
-    the last piece (lowest blocks + input embeddings of the tower that finishes last) stays exposed."""
+    asynchronously (RCCL runs it on its own stream, ordered after the launches enqueued so far on the issuing
+    stream) and overlaps the rest of the backward.  xGMI is point-to-point, so a ring all-reduce of the 600 MB
+    buffer costs milliseconds: only the last piece (lowest blocks + input embeddings of the tower that finishes
+    last) stays exposed.
 
-    def __init__(self, model, pieces_per_tower: Optional[int] = None):
+    Several passes through one tower in a step (``sim_entity`` with alignment, the role descriptions of the
+    ``train_arg`` branch) all accumulate into the same gradient range.  The model reports every tower forward that
+    will need a backward (``note_forward``); a range is handed to RCCL only during the LAST outstanding backward
+    of its tower, and that backward's stream first waits on events recorded behind the gradient writes of the
+    earlier passes -- so no reduction can start, on any stream, while a write to its range is still to come.
+    Whatever was not reduced eagerly (a tower whose pass count is unknown, logit_scale) is reduced by
+    ``finish()``, which runs as an autograd final callback at the end of ``backward()`` -- the gradients are
+    averaged when ``backward()`` returns, as under DDP -- and may also be called explicitly (a second call is a
+    no-op)."""
+
+    TOWERS = ("visual", "text")
+
+    def __init__(self, model, pieces_per_tower: Optional[int] = None, auto_finish: bool = True):
         self.model = model
         if pieces_per_tower is None:
             pieces_per_tower = int(os.environ.get("CE_GRAD_PIECES", "3"))
         self.pieces = max(1, int(pieces_per_tower))
+        self.auto_finish = auto_finish
         self.pending = []
-        self.done = set()
-        self.progress = {}
+        self._reset()
         model.grad_sync = self            # callable: (model, tower, upto_layer=None); also queried for layer_cuts
 
+    def _reset(self):
+        self.done = set()
+        self.progress = {}
+        self.expected = {t: 0 for t in self.TOWERS}      # tower forwards of this step that recorded a graph
+        self.seen = {t: 0 for t in self.TOWERS}          # tower backwards completed this step
+        self.fences = {t: [] for t in self.TOWERS}       # events behind the gradient writes of non-final passes
+        self.dirty = False
+        self._cb_queued = False
+
+    # ---- called by the model -------------------------------------------------------------------------------
+    def note_forward(self, tower: str):
+        """A forward through ``tower`` whose backward will write the tower's gradient range."""
+        self.expected[tower] += 1
+        self.dirty = True
+
+    def _is_last_pass(self, tower: str) -> bool:
+        return self.expected[tower] > 0 and self.seen[tower] + 1 == self.expected[tower]
+
     def layer_cuts(self, tower: str, layers: int):
-        """Blocks at which a tower's backward pauses to hand over gradients: ``pieces`` roughly equal groups."""
-        if not active() or self.pieces < 2 or tower in self.done:
+        """Blocks at which a tower's backward pauses to hand over gradients: ``pieces`` roughly equal groups.
+        None for any pass but the last one through the tower (its range will be written again)."""
+        if not active() or self.pieces < 2 or tower in self.done or not self._is_last_pass(tower):
             return []
         cuts = sorted({(layers * k) // self.pieces for k in range(1, self.pieces)}, reverse=True)
         return [c for c in cuts if 0 < c < layers]
@@ -171,10 +222,38 @@ class GradSync:
         a, b = self.model._ranges[name]
         self._reduce_range(a, b, async_op)
 
+    def _join_fences(self, name: str):
+        """Order the current stream behind the gradient writes of this tower's earlier passes."""
+        if self.fences[name]:
+            cur = torch.cuda.current_stream()
+            for ev in self.fences[name]:
+                cur.wait_event(ev)
+            self.fences[name] = []
+
     def _on_tower(self, model, name: str, upto_layer: Optional[int] = None):
-        if not active() or name in self.done:
+        if not active():
             return
-        # a tower that runs several passes per step (sim_entity, region branch) is reduced again at finish()
+        self.dirty = True
+        if self.auto_finish and not self._cb_queued:
+            # we are inside backward(): run finish() when the whole graph has been processed (DDP does the same)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._finish_callback)
+                self._cb_queued = True
+            except RuntimeError:          # not inside a backward pass (direct call in a test)
+                pass
+        last = self._is_last_pass(name)
+        if upto_layer is None:
+            self.seen[name] += 1
+        if name in self.done:
+            return
+        if not last:
+            if upto_layer is None and model._flat_grad.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.fences[name].append(ev)
+            return
+        if model._flat_grad.is_cuda:
+            self._join_fences(name)
         a, b = model._ranges[name]
         start = self.progress.get(name, a)
         end = b if upto_layer is None else model._layer_end[name][upto_layer]
@@ -185,23 +264,55 @@ class GradSync:
 
     __call__ = _on_tower
 
-    def finish(self, passes_per_tower: int = 1):
-        if not active():
+    def _finish_callback(self):
+        self._cb_queued = False
+        self.finish()
+
+    def finish(self, passes_per_tower: Optional[int] = None):
+        """Reduce what the backward hooks have not, wait for the pending pieces, reset for the next step.
+        ``passes_per_tower`` is accepted for compatibility and ignored (passes are counted, see class docstring).
+        Call from the stream the step is issued on (every tower backward has made that stream wait for its
+        gradient writes, functional._publish_to_main)."""
+        if not active() or not self.dirty:
+            self._reset()
             return
-        if passes_per_tower > 1:
-            for h in self.pending:
-                h.wait()
-            self.pending = []
-            for name in ("visual", "text"):
-                self._reduce(name, async_op=False)
-        else:
-            for name in ("visual", "text"):
-                if name not in self.done:
-                    a, b = self.model._ranges[name]
-                    self._reduce_range(self.progress.get(name, a), b, async_op=False)
+        cuda = self.model._flat_grad.is_cuda
+        for name in self.TOWERS:
+            if name not in self.done:
+                if cuda:
+                    self._join_fences(name)
+                a, b = self.model._ranges[name]
+                self._reduce_range(self.progress.get(name, a), b, async_op=False)
         self._reduce("head", async_op=False)
         for h in self.pending:
             h.wait()
         self.pending = []
-        self.done = set()
-        self.progress = {}
+        self._reset()
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """Call-site replacement for ``torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu],
+    find_unused_parameters=True)`` (train.py:222-225).  torch's own wrapper cannot drive this model: its reducer
+    waits for autograd hooks on every parameter, and the HIP backward writes parameter gradients as side effects of
+    three coarse nodes, so those hooks never fire (the model raises if it finds itself inside torch's wrapper).
+    This class keeps the contract the reference's loop relies on -- ``wrapped(image, text, ...)`` forwards to the
+    model, ``wrapped.module`` is the model (engine.py:52-61), gradients are averaged over ranks by the time
+    ``backward()`` returns -- by installing ``GradSync``.  Extra torch keyword arguments are accepted and ignored."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True, process_group=None,
+                 bucket_cap_mb=None, find_unused_parameters=False, **ignored):
+        super().__init__()
+        if process_group is not None:
+            raise NotImplementedError("only the default process group is supported")
+        self.module = module
+        self.device_ids = device_ids
+        self.grad_sync = GradSync(module)
+        if is_dist() and world_size() > 1:      # DDP broadcasts rank 0's parameters at construction
+            with torch.no_grad():
+                for p in module.parameters():
+                    dist.broadcast(p.data, src=0)
+            if hasattr(module, "mark_operands_stale"):
+                module.mark_operands_stale()
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

@@ -16,35 +16,63 @@ from .functional import logits_from_features
 from .losses import CriterionAlignment, CriterionContrastive
 
 
+def _unwrap(model):
+    """``DistributedDataParallel(model)`` (ours, train.py:222-225) -> the CLIP module (engine.py:52,57-61)."""
+    return model.module if isinstance(model, D.DistributedDataParallel) else model
+
+
 def contrastive_step_losses(model, criterion: CriterionContrastive, image, text, labels_per_image, labels_per_text,
-                            index_pos, global_batch: bool = True) -> Dict[str, torch.Tensor]:
+                            index_pos, global_batch: bool = True, train_arg=None, bboxs=None, bbox_desc_vec=None,
+                            bbox_label_vec=None) -> Dict[str, torch.Tensor]:
     """Forward + criterion.  ``global_batch`` (W > 1): logits_per_image = s * I_local @ T_all^T,
-    logits_per_text = s * T_local @ I_all^T with labels from ``distributed.global_labels``."""
+    logits_per_text = s * T_local @ I_all^T with labels from ``distributed.global_labels``.  With ``train_arg``
+    (model_clip.py:419-488) the two region / argument losses join the dict as ``loss_bbox`` / ``loss_arg``; they
+    are per-image sums over the local batch, no exchange."""
+    model = _unwrap(model)
+    extra = {}
     if D.active() and global_batch:
-        fi, ft = model.encode_both(image, text)
+        if train_arg is None:
+            fi, ft = model.encode_both(image, text)
+        else:
+            fi, ft, loss_bbox, loss_arg = model.encode_with_regions(image, text, train_arg, bboxs, bbox_desc_vec,
+                                                                    bbox_label_vec)
+            extra = {"loss_bbox": loss_bbox, "loss_arg": loss_arg}
         fi_all, ft_all = D.gather_feature_pair(fi, ft)
         overbatch = model.constrastive_overbatch
         lpi, _ = logits_from_features(fi, ft_all if overbatch else ft, model.logit_scale, overbatch, want="image")
         _, lpt = logits_from_features(fi_all, ft, model.logit_scale, True, want="text")
-    else:
+    elif train_arg is None:
         lpi, lpt = model(image, text)
-    return criterion(lpi, lpt, labels_per_image, labels_per_text, index_pos=index_pos,
-                     constrastive_overbatch=model.constrastive_overbatch)
+    else:
+        lpi, lpt, loss_bbox, loss_arg = model(image, text, train_arg, bboxs, bbox_desc_vec, bbox_label_vec)
+        extra = {"loss_bbox": loss_bbox, "loss_arg": loss_arg}
+    loss_dict = criterion(lpi, lpt, labels_per_image, labels_per_text, index_pos=index_pos,
+                          constrastive_overbatch=model.constrastive_overbatch)
+    loss_dict.update(extra)
+    return loss_dict
 
 
 def train_step(model, criterion, optimizer, image, text, labels_per_image, labels_per_text, index_pos,
                grad_sync: Optional[D.GradSync] = None, criterion_ot: Optional[CriterionAlignment] = None,
                object_vec=None, entitytxt_vec=None, object_num=None, entitytxt_num=None,
-               check_finite: bool = False) -> Dict[str, torch.Tensor]:
-    """``check_finite`` reproduces engine.py:70-81 (all-rank mean of the losses, ``.item()``, stop on a non-finite
-    value); it costs the host synchronisation the reference pays every step, so it is off by default."""
+               check_finite: bool = False, train_arg=None, bboxs=None, bbox_desc_vec=None,
+               bbox_label_vec=None) -> Dict[str, torch.Tensor]:
+    """One iteration of engine.py:48-95.  BASELINE config 4 is this call with ``criterion_ot`` + the object / entity
+    tensors (``model.alignment``) and ``train_arg`` + boxes in ONE step, as the reference's forward takes them
+    (model_clip.py:419-528, engine.py:57-63).  ``check_finite`` reproduces engine.py:70-81 (all-rank mean of the
+    losses, ``.item()``, stop on a non-finite value); it costs the host synchronisation the reference pays every
+    step, so it is off by default."""
+    wrapped = model
+    model = _unwrap(model)
+    if grad_sync is None and wrapped is not model:
+        grad_sync = wrapped.grad_sync
     optimizer.zero_grad()
-    loss_dict = contrastive_step_losses(model, criterion, image, text, labels_per_image, labels_per_text, index_pos)
-    passes = 1
+    loss_dict = contrastive_step_losses(model, criterion, image, text, labels_per_image, labels_per_text, index_pos,
+                                        train_arg=train_arg, bboxs=bboxs, bbox_desc_vec=bbox_desc_vec,
+                                        bbox_label_vec=bbox_label_vec)
     if model.alignment and criterion_ot is not None:
         image_features, text_features = model.sim_entity(object_vec, entitytxt_vec)       # engine.py:57-63
         loss_dict.update(criterion_ot(text_features, image_features, entitytxt_num, object_num))
-        passes = 2
     losses = sum(loss for loss in loss_dict.values())                                      # engine.py:67
     if check_finite:
         reduced = D.reduce_dict({k: v.detach() for k, v in loss_dict.items()})
@@ -55,6 +83,6 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
             sys.exit(1)
     losses.backward()
     if grad_sync is not None:
-        grad_sync.finish(passes_per_tower=passes)
+        grad_sync.finish()             # no-op when the autograd final callback has already run it
     optimizer.step()                                                                       # clip + Adam
     return loss_dict

@@ -212,7 +212,7 @@ class CLIP(nn.Module):
     # rebuilt lazily by _prepare(); only the parameters and the plain attributes travel --------------------------
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
-                "_tjobs_n", "_tjobs_tiles", "_mirror_fresh", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
+                "_tjobs_n", "_tjobs_tiles", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
                 "_side_streams", "_main_stream", "_pack_cache", "grad_sync")
 
     def __getstate__(self):
@@ -437,7 +437,8 @@ class CLIP(nn.Module):
         raw = bytes(jobs)
         self._tjobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._tjobs_n, self._tjobs_tiles = len(names_t), tiles
-        self._mirror_fresh = False        # True when the Adam kernel has just written _flat16
+        self._mirror_fresh = False        # True when the Adam kernel has just written _flat16 ...
+        self._mirror_versions = None      # ... from masters at these parameter versions
 
         def desc(prefix: str, tr: Transformer, tokens: int, causal: bool):
             arr = (_BlockParams * tr.layers)()
@@ -478,7 +479,9 @@ class CLIP(nn.Module):
             return
         s = stream()
         cl = lib()
-        if not self._mirror_fresh:
+        # the bf16 mirror written by the fused Adam kernel is only as good as the masters it was cast from: if any
+        # master has moved since (load_state_dict, a stock optimiser step, an EMA swap), cast again
+        if not (self._mirror_fresh and vers == self._mirror_versions):
             # masters changed outside the fused optimiser: rebuild the whole bf16 mirror (one launch)
             check(cl.ce_cast_bf16(ptr(self._flat), ptr(self._flat16), c_long(self._flat.numel()), s), "ce_cast_bf16")
         check(cl.ce_multi_transpose_bf16(ptr(self._tjobs), c_int(self._tjobs_n), c_int(self._tjobs_tiles), s),
@@ -494,6 +497,7 @@ class CLIP(nn.Module):
         only the transposed copies need rebuilding."""
         self._versions = None
         self._mirror_fresh = mirror_fresh
+        self._mirror_versions = tuple(self._pmap[n]._version for n in self._cast_list) if mirror_fresh else None
 
     def _ready(self):
         if not self._flat_ok():
@@ -506,19 +510,36 @@ class CLIP(nn.Module):
         self.refresh_operands()
 
     # ---- encoders -------------------------------------------------------------------------
+    def _note_pass(self, tower: str):
+        """Bookkeeping before a tower forward: refuse torch's DistributedDataParallel (its reducer waits for
+        per-parameter autograd hooks that the HIP backward never fires -- an "unchanged" train.py would die on the
+        second iteration inside the reducer with an unrelated message) and tell the gradient exchange that one more
+        backward will write this tower's gradient range."""
+        from torch.nn.parallel import DistributedDataParallel as TorchDDP
+        if getattr(TorchDDP, "_active_ddp_module", None) is not None:
+            raise RuntimeError(
+                "clip_event_amd.CLIP cannot run inside torch.nn.parallel.DistributedDataParallel: parameter gradients "
+                "are written by the HIP backward as side effects, so DDP's autograd hooks never fire.  Wrap the model "
+                "with clip_event_amd.distributed.DistributedDataParallel(model, device_ids=[gpu]) instead (same call "
+                "site, train.py:222-225; see INTEGRATION.md).")
+        if self.grad_sync is not None and torch.is_grad_enabled() and hasattr(self.grad_sync, "note_forward"):
+            self.grad_sync.note_forward(tower)
+
     def encode_image(self, image, use_grid: bool = False):
         """model_clip.py:390-391 -> VisualTransformer.forward (:232-263)."""
         self._ready()
+        self._note_pass("visual")
         from .functional import EncodeImageFn
         return EncodeImageFn.apply(image, self._trigger, self, bool(use_grid))
 
     def encode_text(self, text):
         """model_clip.py:398-417."""
         self._ready()
+        self._note_pass("text")
         from .functional import EncodeTextFn
         return EncodeTextFn.apply(text, self._trigger, self)
 
-    def encode_both(self, image, text):
+    def encode_both(self, image, text, use_grid: bool = False):
         """Image and text towers of one step.  They are independent until the logits, so with
         ``tower_streams`` (default) they run on two HIP streams: the ramp-up / tail of every kernel of one
         tower (and the CUs a ragged tile grid leaves idle) is filled by the other tower's kernels.  The
@@ -526,7 +547,7 @@ class CLIP(nn.Module):
         self._ready()
         if not getattr(self, "tower_streams", True):
             self._main_stream = None
-            return self.encode_image(image), self.encode_text(text)
+            return self.encode_image(image, use_grid), self.encode_text(text)
         if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != self._flat.device:
             # the image tower is the longer chain: its stream gets the higher priority, the text tower's kernels fill
             # in around it (measured 0.7 % on the step; CE_IMG_STREAM_PRIORITY / CE_TXT_STREAM_PRIORITY override)
@@ -539,7 +560,7 @@ class CLIP(nn.Module):
         s_img.wait_stream(cur)
         s_txt.wait_stream(cur)
         with torch.cuda.stream(s_img):
-            image_features = self.encode_image(image)
+            image_features = self.encode_image(image, use_grid)
         with torch.cuda.stream(s_txt):
             text_features = self.encode_text(text)
         cur.wait_stream(s_img)
@@ -554,20 +575,24 @@ class CLIP(nn.Module):
         if train_arg is None:
             image_features, text_features = self.encode_both(image, text)
             return logits_from_features(image_features, text_features, self.logit_scale, self.constrastive_overbatch)
-        image_features = self.encode_image(image, use_grid=train_arg is not None)
-        if train_arg is not None:
-            from .region import region_losses
-            B = image_features.size(0)
-            pn = self.visual.patch_num
-            grid_features = image_features[:, 1:, :].reshape(B, pn, pn, -1)
-            image_features = image_features[:, 0, :]
-            loss_per_bbox, loss_per_arg = region_losses(self, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg)
-        text_features = self.encode_text(text)
+        image_features, text_features, loss_per_bbox, loss_per_arg = self.encode_with_regions(
+            image, text, train_arg, bboxs, bbox_desc_vec, bbox_label_vec)
         logits_per_image, logits_per_text = logits_from_features(
             image_features, text_features, self.logit_scale, self.constrastive_overbatch)
-        if train_arg is not None:
-            return logits_per_image, logits_per_text, loss_per_bbox, loss_per_arg
-        return logits_per_image, logits_per_text
+        return logits_per_image, logits_per_text, loss_per_bbox, loss_per_arg
+
+    def encode_with_regions(self, image, text, train_arg, bboxs, bbox_desc_vec, bbox_label_vec):
+        """The ``train_arg`` half of model_clip.py:419-488: both towers (image tower with its patch grid), then the
+        region / argument losses from the grid.  Returns ``(image_features [B,E], text_features, loss_per_bbox,
+        loss_per_arg)``; the caller forms the logits (locally, or over the all-gathered batch)."""
+        from .region import region_losses
+        image_features, text_features = self.encode_both(image, text, use_grid=True)
+        B = image_features.size(0)
+        pn = self.visual.patch_num
+        grid_features = image_features[:, 1:, :].reshape(B, pn, pn, -1)
+        image_features = image_features[:, 0, :]
+        loss_per_bbox, loss_per_arg = region_losses(self, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg)
+        return image_features, text_features, loss_per_bbox, loss_per_arg
 
     def sim_entity(self, img_obj, txt_ent):
         """model_clip.py:531-552: un-normalised object / entity features."""

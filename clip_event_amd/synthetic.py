@@ -85,3 +85,38 @@ def synthetic_model(geometry: str = "vit_b32", seed: int = 0):
     finally:
         torch.random.set_rng_state(state)
     return model
+
+
+def synthetic_entities(batch: int, resolution: int = 224, context_length: int = 77, vocab_size: int = 49408,
+                       seed: int = 999, max_objects: int = 6, max_entities: int = 10):
+    """Inputs of ``sim_entity`` / ``CriterionAlignment`` (engine.py:57-63) as SURVEY 8(d) c4 lays them out: per
+    image 1 + U[0, max_objects] object crops (slot 0 = the whole image, model_clip.py:686) and U[1, max_entities]
+    entity mentions, padded to the batch maxima with 0/1 masks.  Returns ``(object_vec [B,O,3,R,R] f32, object_num
+    [B,O] int64, entitytxt_vec [B,M,T] int64, entitytxt_num [B,M] int64)``; padding crops are zeros, padding
+    mentions are the empty caption (SOT EOT)."""
+    rng = np.random.default_rng(seed)
+    n_obj = 1 + rng.integers(0, max_objects + 1, size=batch)
+    n_ent = rng.integers(1, max_entities + 1, size=batch)
+    O, M = int(n_obj.max()), int(n_ent.max())
+    obj = np.zeros((batch, O, 3, resolution, resolution), dtype=np.float32)
+    obj_num = np.zeros((batch, O), dtype=np.int64)
+    ent = np.zeros((batch, M, context_length), dtype=np.int64)
+    ent[:, :, 0] = vocab_size - 2
+    ent[:, :, 1] = vocab_size - 1
+    ent_num = np.zeros((batch, M), dtype=np.int64)
+    for b in range(batch):
+        obj[b, :n_obj[b]] = rng.standard_normal((n_obj[b], 3, resolution, resolution), dtype=np.float32)
+        obj_num[b, :n_obj[b]] = 1
+        toks = synthetic_tokens(int(n_ent[b]), context_length, vocab_size, seed=int(rng.integers(1 << 30)), min_len=1,
+                                max_len=min(6, context_length - 2)).numpy()
+        ent[b, :n_ent[b]] = toks
+        ent_num[b, :n_ent[b]] = 1
+    return torch.from_numpy(obj), torch.from_numpy(obj_num), torch.from_numpy(ent), torch.from_numpy(ent_num)
+
+
+def synthetic_role_texts(bboxs, context_length: int = 77, vocab_size: int = 49408, seed: int = 999, max_len: int = 12):
+    """One token row per box of every image (``bbox_desc_vec`` / ``bbox_label_vec`` of model_clip.py:419):
+    list[B] of int64 [n_roles, T]."""
+    rng = np.random.default_rng(seed)
+    return [synthetic_tokens(len(b), context_length, vocab_size, seed=int(rng.integers(1 << 30)), min_len=1,
+                             max_len=min(max_len, context_length - 2)) for b in bboxs]

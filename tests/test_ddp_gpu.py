@@ -1,0 +1,52 @@
+"""W = 2 on one GPU: the HIP model through ``engine.train_step`` + the real ``GradSync`` in two fresh child
+processes (gloo, both on cuda:0) against the single-process run on the concatenated batch (SURVEY.md 8(e), H3;
+reference contract: DistributedDataParallel, train.py:222-225; gather pattern utils.py:192-206).  Cases: K = 1,
+K = 5 hard negatives, alignment (two passes per tower), the region branch (three text passes), and config 4's
+combination."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(script, case, W=2, timeout=420, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(W):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(W), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CASE=case, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("case", ["k1", "k5", "align", "region", "all"])
+def test_two_rank_step_equals_concatenated_batch(case):
+    rcs, outs = run_ranks("ddp_child.py", case)
+    print(outs[0][-3000:])
+    assert rcs == [0, 0], "\n".join(o[-3000:] for o in outs)
+    assert f"[{case}] OK" in outs[0]

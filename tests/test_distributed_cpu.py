@@ -78,3 +78,139 @@ def test_global_batch_gradient_equals_single_process(tmp_path, paired):
     assert torch.allclose(got["Wi"], Wi.grad, atol=1e-5, rtol=1e-4)
     assert torch.allclose(got["Wt"], Wt.grad, atol=1e-5, rtol=1e-4)
     assert torch.allclose(got["ls"], ls.grad, atol=1e-5, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GradSync itself (layer_cuts, pass counting, pieces, finish) on gloo with a stand-in for the flat gradient buffer
+
+class _FlatStandIn:
+    """What GradSync touches of the model: the flat gradient buffer, the per-group ranges and the per-block
+    prefix ends (model.CLIP._prepare)."""
+    LAYERS = 4
+
+    def __init__(self):
+        blk, headn, tail = 6, 2, 3
+        self._ranges, self._layer_end = {}, {}
+        off = 0
+        self._ranges["head"] = (off, off + 1)
+        off += 1
+        for tower in ("visual", "text"):
+            start = off
+            off += headn
+            self._layer_end[tower] = {}
+            for b in reversed(range(self.LAYERS)):
+                off += blk
+                self._layer_end[tower][b] = off
+            off += tail
+            self._ranges[tower] = (start, off)
+        self._flat_grad = torch.zeros(off)
+        self.grad_sync = None
+
+    def backward_pass(self, tower, contribution):
+        """Mirror of functional._tower_backward + the tower node's tail: accumulate ``contribution`` range by
+        range, calling the hooks exactly where the HIP backward does."""
+        gs = self.grad_sync
+        a, b = self._ranges[tower]
+        cuts = gs.layer_cuts(tower, self.LAYERS)
+        pos = a
+        for lo in list(cuts) + [0]:
+            end = self._layer_end[tower][lo]
+            self._flat_grad[pos:end] += contribution[pos - a:end - a]
+            pos = end
+            if lo > 0:
+                gs(self, tower, upto_layer=lo)
+        self._flat_grad[pos:b] += contribution[pos - a:b - a]
+        gs(self, tower)
+
+
+def _gradsync_worker(rank, W, port, passes, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from clip_event_amd import distributed as D
+    m = _FlatStandIn()
+    sync = D.GradSync(m, pieces_per_tower=3)
+    results = []
+    for step in range(2):                     # two steps: the bookkeeping must reset
+        m._flat_grad.zero_()
+        g = torch.Generator().manual_seed(100 * step + rank)
+        contrib = {t: [torch.randn(m._ranges[t][1] - m._ranges[t][0], generator=g) for _ in range(passes[t])]
+                   for t in ("visual", "text")}
+        for t in ("visual", "text"):
+            for _ in range(passes[t]):
+                sync.note_forward(t)
+        if passes.get("unnoted"):              # a backward whose forward was never reported: nothing eager, finish() reduces
+            sync.expected["text"] = 0
+        cuts_seen = {}
+        # autograd order: the passes created last run first; the towers interleave
+        for k in reversed(range(max(passes["visual"], passes["text"]))):
+            for t in ("text", "visual"):
+                if k < passes[t]:
+                    cuts_seen.setdefault(t, []).append(len(sync.layer_cuts(t, m.LAYERS)))
+                    m.backward_pass(t, contrib[t][k])
+        m._flat_grad[0] += float(rank + 1)     # logit_scale
+        sync.finish()
+        sync.finish()                           # idempotent
+        assert not sync.dirty and not sync.pending
+        for t in ("visual", "text"):
+            n = len(cuts_seen[t])
+            # only the last pass through a tower may be cut into eagerly reduced pieces
+            assert all(c == 0 for c in cuts_seen[t][:-1]), cuts_seen
+            if not (passes.get("unnoted") and t == "text"):
+                assert cuts_seen[t][-1] == 2, cuts_seen
+        results.append((m._flat_grad.clone(), {t: torch.stack(contrib[t]).sum(0) for t in contrib}))
+    gathered = [None] * W
+    dist.all_gather_object(gathered, [(r[0], r[1]) for r in results])
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("passes", [{"visual": 1, "text": 1}, {"visual": 2, "text": 3},
+                                    {"visual": 2, "text": 2, "unnoted": True}])
+def test_gradsync_pieces_and_multi_pass_average(tmp_path, passes):
+    """Every element of the flat gradient buffer ends as the rank mean of the summed per-pass contributions,
+    whatever the number of passes per tower; a range is never reduced before its last write (a piece averaged
+    early and written again would come out as (mean + later)/W, which this catches)."""
+    W = 2
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_gradsync_worker, args=(W, _free_port(), passes, out), nprocs=W, join=True)
+    gathered = torch.load(out, weights_only=False)          # written by this test
+    m = _FlatStandIn()
+    for step in range(2):
+        want = torch.zeros_like(m._flat_grad)
+        for r in range(W):
+            tot = gathered[r][step][1]
+            for t in ("visual", "text"):
+                a, b = m._ranges[t]
+                want[a:b] += tot[t] / W
+            want[0] += (r + 1) / W
+        for r in range(W):
+            assert torch.allclose(gathered[r][step][0], want, atol=1e-6), (step, r)
+
+
+def test_local_only_switch():
+    from clip_event_amd import distributed as D
+    assert not D.active() and D.world_size() == 1 and D.rank() == 0
+    with D.local_only():
+        assert not D.active()
+    assert D._LOCAL_ONLY == 0
+
+
+def test_ddp_wrapper_surface_and_torch_ddp_is_refused():
+    """train.py:222-225's call site: our wrapper exposes ``.module`` and forwards calls; the model refuses to run
+    inside torch's DistributedDataParallel with a message that names the replacement."""
+    import torch.nn.parallel as P
+    from clip_event_amd import distributed as D
+    from clip_event_amd.model import CLIP
+    m = CLIP(32, 32, 1, 64, 16, 8, 64, 64, 1, 1)
+    w = D.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+    assert w.module is m and isinstance(m.grad_sync, D.GradSync)
+    assert all(k.startswith("module.") for k in w.state_dict())
+    P.DistributedDataParallel._active_ddp_module = object()
+    try:
+        with pytest.raises(RuntimeError, match="clip_event_amd.distributed.DistributedDataParallel"):
+            m._note_pass("visual")
+    finally:
+        P.DistributedDataParallel._active_ddp_module = None

@@ -44,3 +44,18 @@ def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.detach().double().cpu().flatten()
     b = b.detach().double().cpu().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def sample_agreement(t: torch.Tensor, gold: dict):
+    """Direction check on the 32 sampled values a golden summary stores (``idx`` / ``val``, make_golden.py:70-75):
+    returns ``(cosine of the sampled vectors, max |difference| / RMS of the golden tensor)``.  A gradient with the
+    right norm but the wrong sign, layout or transposition fails this although its norm matches.  ``(None, 0.0)``
+    when the golden samples are all (near) zero."""
+    _, _, vals = summary_of(t, gold["idx"])
+    ref = np.asarray(gold["val"], dtype=np.float64)
+    rms = gold["norm"] / max(t.numel(), 1) ** 0.5
+    err = float(np.abs(vals - ref).max() / max(rms, 1e-30))
+    nr = float(np.linalg.norm(ref))
+    if nr <= 1e-3 * rms * len(ref) ** 0.5:
+        return None, err
+    return float(vals @ ref / (np.linalg.norm(vals) * nr + 1e-300)), err
