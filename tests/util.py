@@ -48,14 +48,16 @@ def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
 
 def sample_agreement(t: torch.Tensor, gold: dict):
     """Direction check on the 32 sampled values a golden summary stores (``idx`` / ``val``, make_golden.py:70-75):
-    returns ``(cosine of the sampled vectors, max |difference| / RMS of the golden tensor)``.  A gradient with the
+    returns ``(cosine of the sampled vectors, max |difference| / scale)`` with scale = the larger of the golden tensor's
+    RMS and the RMS of its sampled values (a sparse gradient such as the token embedding's has samples far above the
+    tensor RMS).  A gradient with the
     right norm but the wrong sign, layout or transposition fails this although its norm matches.  ``(None, 0.0)``
     when the golden samples are all (near) zero."""
     _, _, vals = summary_of(t, gold["idx"])
     ref = np.asarray(gold["val"], dtype=np.float64)
     rms = gold["norm"] / max(t.numel(), 1) ** 0.5
-    err = float(np.abs(vals - ref).max() / max(rms, 1e-30))
     nr = float(np.linalg.norm(ref))
+    err = float(np.abs(vals - ref).max() / max(rms, nr / len(ref) ** 0.5, 1e-30))
     if nr <= 1e-3 * rms * len(ref) ** 0.5:
         return None, err
     return float(vals @ ref / (np.linalg.norm(vals) * nr + 1e-300)), err
