@@ -1,0 +1,117 @@
+// Pieces shared by the NT GEMM kernels (bf16: gemm.hip, fp8: gemm_fp8.hip): argument block, XCD-aware tile order and
+// the fused epilogues.  Included inside each file's anonymous namespace.
+#pragma once
+#include "common.hpp"
+#include "../../include/clip_event_hip.h"
+
+struct NTArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* B; long ldb;
+    int M, N, K;
+    const float* bias;
+    const float* resid; long ldr;
+    void* out; long ldo;
+    bf16_t* out2; long ldo2;
+    const bf16_t* aux; long ldaux;
+    int tiles_m, tiles_n;
+    const float* sa = nullptr;   // fp8 path: per-row dequantisation scales of A (M) ...
+    const float* sb = nullptr;   // ... and of B (N); the epilogue multiplies the accumulator by sa[m] * sb[n]
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
+    // range of tiles so neighbouring tiles (same A row panel) hit the same L2.  Bijective
+    // for any nwg.  Speed only, never correctness.
+    int xcd = bid & 7, local = bid >> 3;
+    int q = nwg >> 3, r = nwg & 7;
+    int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + local;
+}
+
+// fused epilogue for one lane's 4 consecutive output columns n..n+3 of row m
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4 v) {
+    if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                  EPI == CE_EPI_BIAS_F32) {
+        v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
+    } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
+        v += *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
+    } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
+        // out = pre-activation a (bf16, kept for the backward), out2 = QuickGELU(a) (bf16)
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+        u32x2 g = {pack_bf2(quick_gelu_f(v[0]), quick_gelu_f(v[1])), pack_bf2(quick_gelu_f(v[2]), quick_gelu_f(v[3]))};
+        *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = g;
+    } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        // out = acc * QuickGELU'(a), a = saved bf16 pre-activation
+        u32x2 a = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
+        u32x2 o = {pack_bf2(v[0] * quick_gelu_grad_f(bf_lo(a[0])), v[1] * quick_gelu_grad_f(bf_hi(a[0]))),
+                   pack_bf2(v[2] * quick_gelu_grad_f(bf_lo(a[1])), v[3] * quick_gelu_grad_f(bf_hi(a[1])))};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    }
+}
+
+// Fused bias gradient of the GELUGRAD epilogue: every lane holds partial column sums of its 8 columns
+// (n_local .. n_local+7 of the workgroup's 256-column tile); the 8 row-phases of a wave and the two waves stacked
+// along M share columns.  Each lane parks its 8 partial sums in a [16][256] LDS strip (plain 16-byte stores, row =
+// 8*wm + row-phase), then thread c adds column c's 16 entries and issues the workgroup's ONE global atomic for
+// that column: 4 atomic wave-instructions per workgroup instead of 64, no cross-lane shuffles.
+__device__ __forceinline__ void wg_colsum_flush(char* smem, float* __restrict__ colsum, int n0, int N, int n_local,
+                                                int srow, const f32x4& cs0, const f32x4& cs1, int bn = 256) {
+    constexpr int SROW = 264;                              // floats: 256 + 8 pad (rows shift by 8 banks)
+    float* strip = reinterpret_cast<float*>(smem);
+    __syncthreads();                                       // every wave is done with its epilogue slice
+    *reinterpret_cast<f32x4*>(strip + srow * SROW + n_local) = cs0;
+    *reinterpret_cast<f32x4*>(strip + srow * SROW + n_local + 4) = cs1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < bn; i += blockDim.x) {      // bn = columns of the workgroup's tile
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += strip[r * SROW + i];
+        if (n0 + i < N && t != 0.f) atomicAdd(colsum + n0 + i, t);
+    }
+}
+
+// fused epilogue for 8 consecutive output columns n..n+7 of row m (bias already added)
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x4 v0, f32x4 v1, f32x4& cs0, f32x4& cs1) {
+    if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16) {
+        u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    } else if constexpr (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + 4) = v1;
+    } else if constexpr (EPI == CE_EPI_BIAS_RESID_F32) {
+        const float* r = p.resid + (long)m * p.ldr + n;
+        v0 += *reinterpret_cast<const f32x4*>(r);
+        v1 += *reinterpret_cast<const f32x4*>(r + 4);
+        float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + 4) = v1;
+    } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
+        u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+        u32x4 g = {pack_bf2(quick_gelu_f(v0[0]), quick_gelu_f(v0[1])), pack_bf2(quick_gelu_f(v0[2]), quick_gelu_f(v0[3])),
+                   pack_bf2(quick_gelu_f(v1[0]), quick_gelu_f(v1[1])), pack_bf2(quick_gelu_f(v1[2]), quick_gelu_f(v1[3]))};
+        *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + n) = g;
+    } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        u32x4 a = *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + n);
+        f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
+                    v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
+        f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
+                    v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
+        cs0 += r0;      // column sums of the result = bias gradient of the Linear whose pre-activation this is
+        cs1 += r1;
+        u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
+    }
+}
+

@@ -1,0 +1,326 @@
+// fp8 (OCP e4m3) NT GEMM for the towers' Linear layers -- BASELINE config 5's "fp8 MFMA weight path" (gfx950 / CDNA4).
+//
+//   ce_quant_rows_fp8 : q[r,:] = e4m3(x[r,:] * 2^e_r), scale[r] = 2^-e_r, 2^e_r * amax_r in (224, 448]   (bf16 -> fp8)
+//   ce_gemm_nt_fp8    : C[m,n] = sa[m] * sb[n] * sum_k A8[m,k] * B8[n,k]   (+ the fused epilogues of ce_gemm_nt)
+//
+// Which tensors a low-precision path may touch follows the reference's convert_weights (model_clip.py:554-575: the
+// Linear / MHA projection weights; LayerNorm, embeddings, biases, the residual stream and the logits stay fp32).  Both
+// GEMM operands are e4m3 with one fp32 scale per ROW (per token for activations, per output channel for weights); the
+// scales multiply the fp32 accumulator in the epilogue, so the MFMA runs on unit block scales.
+//
+// Kernel = the 256-column LDS-DMA kernel of gemm.hip with 128-deep K tiles: an LDS row is again 128 bytes (128 fp8
+// values instead of 64 bf16), so the DMA map, the source-side XOR swizzle and the conflict-free ds_read_b128 fragment
+// reads are unchanged; one v_mfma_scale_f32_16x16x128_f8f6f4 (32 cycles, MI355X_MICROARCH.md "Matrix cores": twice the
+// bf16 rate) replaces two v_mfma_f32_16x16x32_bf16.  A lane's 32 k-values are the two 16-byte chunks (kc, 4 + kc) of
+// its row -- the dot product does not care about the order of k as long as both operands use the same one.
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "common.hpp"
+#include "../../include/clip_event_hip.h"
+
+namespace {
+
+#include "gemm_common.hpp"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+constexpr int F8_BK = 128;                       // fp8 elements (= bytes) per K tile
+constexpr int F8H_LDS_BYTES = 2 * (160 + 128) * 128;   // 72 KiB: 160x128 tile, two stages
+constexpr int F8_LDS_BYTES = 8 * 64 * 272;             // 136 KiB: two stages of a 256x256 tile / 8 epilogue slices
+
+template <int EPI, int TM, int WN>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_nt8_kernel(NTArgs p) {
+    constexpr int NW = 2 * WN;
+    constexpr int BN = 64 * WN;
+    constexpr int BM = 32 * TM;
+    constexpr int A_BYTES = BM * F8_BK;
+    constexpr int B_BYTES = BN * F8_BK;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 8;                             // 1-KiB DMA instructions per A tile
+    constexpr int A_PER_WAVE = (A_INSTR + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const char* A8 = reinterpret_cast<const char*>(p.A);
+    const char* B8 = reinterpret_cast<const char*>(p.B);
+
+    // staging: one wave-instruction = 8 rows x 128 B; lane l lands at LDS (row l>>3, position l&7) and fetches
+    // source chunk pos ^ (row&7)
+    const int s_r = lane >> 3, s_pos = lane & 7;
+    const int s_chunk = s_pos ^ s_r;
+    const char* gA[A_PER_WAVE];
+    const char* gB[4];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int row = (wave + NW * i) * 8 + s_r;
+        const int ra = min(m0 + row, p.M - 1);                  // clamp: rows past the edge are never stored
+        gA[i] = A8 + (long)ra * p.lda + s_chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + s_r;
+        const int rb = min(n0 + row, p.N - 1);
+        gB[i] = B8 + (long)rb * p.ldb + s_chunk * 16;
+    }
+    auto stage = [&](int st, int kt) {
+        char* sa = smem + st * STAGE_BYTES;
+        char* sb = sa + A_BYTES + wave * 4096;
+        const int koff = kt * F8_BK;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i)
+            if (wave + NW * i < A_INSTR)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(gA[i] + koff), (lptr_t*)(sa + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gB[i] + koff), (lptr_t*)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / F8_BK;
+    stage(0, 0);
+    __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+
+    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
+    const int c0 = (f_kc ^ f_sw) << 4, c1 = ((4 + f_kc) ^ f_sw) << 4;
+    const int fa_base = (wm * (TM * 16) + f_row) * 128;
+    const int fb_base = A_BYTES + (wn * 64 + f_row) * 128;
+    auto frag = [&](const char* row) -> i32x8 {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(row + c0);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(row + c1);
+        i32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return v;
+    };
+    constexpr int ONE = 0x7f7f7f7f;      // E8M0 block scale 2^0 in every byte
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* st = smem + cur * STAGE_BYTES;
+        i32x8 wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = frag(st + fb_base + t * 2048);
+#pragma unroll
+        for (int mh = 0; mh * 4 < TM; ++mh) {
+            i32x8 af[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (mh * 4 + t < TM) af[t] = frag(st + fa_base + (mh * 4 + t) * 2048);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (mh * 4 + t < TM) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mh * 4 + t][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            wf[nt], af[t], acc[mh * 4 + t][nt], 0, 0, 0, ONE, 0, ONE);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS (as gemm_nt256_kernel), with the two dequantisation scales applied first ----
+    constexpr int EROW = 272;
+    char* ebuf = smem + wave * (64 * EROW);
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;
+    const int gn = n0 + wn * 64 + e_c;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sb0 = {0.f, 0.f, 0.f, 0.f}, sb1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    if (gn < p.N) {
+        sb0 = *reinterpret_cast<const f32x4*>(p.sb + gn);
+        sb1 = *reinterpret_cast<const f32x4*>(p.sb + gn + 4);
+        if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                      EPI == CE_EPI_BIAS_F32) {
+            bias0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+            bias1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+        }
+    }
+#pragma unroll
+    for (int mh = 0; mh * 4 < TM; ++mh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (mh * 4 + t < TM) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    *reinterpret_cast<f32x4*>(ebuf + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) =
+                        acc[mh * 4 + t][nt];
+            }
+        const int gm0 = m0 + wm * (TM * 16) + mh * 64 + e_r;
+        const int its = (TM - mh * 4 >= 4) ? 8 : (TM - mh * 4) * 2;   // 8 rows per iteration
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (it >= its) break;
+            const int m = gm0 + it * 8;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
+            if (m < p.M && gn < p.N) {
+                const float sa = p.sa[m];
+                v0 = v0 * sa * sb0 + bias0;
+                v1 = v1 * sa * sb1 + bias1;
+                nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+            }
+        }
+    }
+    if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        if (p.out2) wg_colsum_flush(smem, reinterpret_cast<float*>(p.out2), n0, p.N, gn - n0, wm * 8 + e_r, cs0, cs1, BN);
+    }
+}
+
+// ---- per-row quantisation: one wave per row, the row held in registers (K <= 4096) ----
+template <int CPL>   // 16-byte chunks (8 bf16) per lane
+__global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q,
+                                                         long ldq, float* __restrict__ scale, int M, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int chunks = K >> 3;
+    const bf16_t* xr = x + (long)row * ldx;
+    u32x4 v[CPL];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (c < chunks) v[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(v[i][e])), fabsf(bf_hi(v[i][e]))));
+    }
+    amax = wave_max(amax);
+    // power-of-two scale: amax = m * 2^k (m in [0.5, 1)) is mapped into (224, 448] by inv = 2^(9-k) (m <= 0.875) or
+    // 2^(8-k).  Multiplying by a power of two is exact, so the bytes depend on nothing but the e4m3 rounding itself
+    // (bit-reproducible on any host), and e4m3 being a floating-point format loses nothing to the coarser scale.
+    const uint32_t ab = __float_as_uint(amax);
+    const bool live = amax >= 7.8886090522101181e-31f;          // 2^-100; smaller rows quantise to zero with scale 1
+    const int e = 9 - ((int)((ab >> 23) & 0xff) - 126) - (((ab & 0x7fffffu) > 0x600000u) ? 1 : 0);
+    const float inv = live ? __uint_as_float((uint32_t)(e + 127) << 23) : 1.0f;
+    if (lane == 0) scale[row] = live ? __uint_as_float((uint32_t)(127 - e) << 23) : 1.0f;
+    uint8_t* qr = q + (long)row * ldq;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= chunks) continue;
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][0]) * inv, bf_hi(v[i][0]) * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][1]) * inv, bf_hi(v[i][1]) * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][2]) * inv, bf_hi(v[i][2]) * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][3]) * inv, bf_hi(v[i][3]) * inv, w1, true);
+        u32x2 o = {(uint32_t)w0, (uint32_t)w1};
+        *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+    }
+}
+
+template <int EPI, int TM, int WN>
+void launch8(NTArgs& a, hipStream_t stream) {
+    static std::once_flag attr;
+    constexpr int LDS = WN == 2 ? F8H_LDS_BYTES : F8_LDS_BYTES;
+    std::call_once(attr, [] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt8_kernel<EPI, TM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    });
+    a.tiles_m = ce_div_up(a.M, 32 * TM);
+    a.tiles_n = ce_div_up(a.N, 64 * WN);
+    hipLaunchKernelGGL((gemm_nt8_kernel<EPI, TM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(128 * WN), LDS, stream, a);
+}
+
+int g_force8 = 0;     // tools: 0 auto, 4/5/6/8 = tile height of the 256-column kernel, 105 = the 160x128 tile
+
+template <int EPI>
+int launch_nt8(NTArgs a, hipStream_t stream) {
+    const double out_b = EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0);
+    CeProfScope prof(CE_PROF_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, 1.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
+    // tile choice as in gemm.hip: rounds over the 256 CUs x cost of a round; the two-workgroup 160x128 tile when its
+    // tiles fit one resident round
+    const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
+    int best = 8;
+    long best_cost = -1;
+    const long tn = ce_div_up(a.N, 256);
+    for (int tm : {8, 6, 5, 4}) {
+        const long tiles = (long)ce_div_up(a.M, 32 * tm) * tn;
+        const long cost = ((tiles + 255) / 256) * (28 + 10 * tm);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = tm; }
+    }
+    const int f = g_force8;
+    if (f == 105 || (f == 0 && half_tiles <= 512)) launch8<EPI, 5, 2>(a, stream);
+    else {
+        switch (f ? f : best) {
+            case 4: launch8<EPI, 4, 4>(a, stream); break;
+            case 5: launch8<EPI, 5, 4>(a, stream); break;
+            case 6: launch8<EPI, 6, 4>(a, stream); break;
+            default: launch8<EPI, 8, 4>(a, stream); break;
+        }
+    }
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" void ce_gemm_nt_fp8_tune(int variant) { g_force8 = variant; }
+
+extern "C" int ce_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, void* stream) {
+    CE_CHECK_ARG(x && q && scale && M > 0, "ce_quant_rows_fp8: null buffer or empty problem");
+    CE_CHECK_ARG(K > 0 && K % 8 == 0 && K <= 4096 && ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K,
+                 "ce_quant_rows_fp8: need K %% 8 == 0, K <= 4096 and 8-element aligned rows (K=%d)", K);
+    CeProfScope prof(CE_PROF_OTHER, 0.0, 3.0 * M * K, (hipStream_t)stream);
+    const int cpl = ce_div_up(K >> 3, 64);
+    const dim3 grid(ce_div_up(M, 4)), block(256);
+    const bf16_t* xs = (const bf16_t*)x;
+    uint8_t* qs = (uint8_t*)q;
+    hipStream_t s = (hipStream_t)stream;
+    if (cpl <= 1) hipLaunchKernelGGL(quant_rows_kernel<1>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
+    else if (cpl <= 2) hipLaunchKernelGGL(quant_rows_kernel<2>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
+    else if (cpl <= 4) hipLaunchKernelGGL(quant_rows_kernel<4>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
+    else hipLaunchKernelGGL(quant_rows_kernel<8>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_gemm_nt_fp8(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, int M,
+                              int N, int K, int epilogue, const float* bias, const float* resid, long ldr, void* out,
+                              long ldo, void* out2, long ldo2, const void* aux, long ldaux, void* stream) {
+    CE_CHECK_ARG(A8 && B8 && sa && sb && out, "ce_gemm_nt_fp8: null buffer");
+    CE_CHECK_ARG(M > 0 && N > 0 && K > 0, "ce_gemm_nt_fp8: empty problem M=%d N=%d K=%d", M, N, K);
+    CE_CHECK_ARG(K % F8_BK == 0 && N % 8 == 0, "ce_gemm_nt_fp8: need K%%128==0 and N%%8==0 (K=%d N=%d)", K, N);
+    CE_CHECK_ARG(lda % 16 == 0 && ldb % 16 == 0 && ldo % 8 == 0 && ldo2 % 8 == 0 && ldaux % 8 == 0,
+                 "ce_gemm_nt_fp8: lda/ldb must be multiples of 16 bytes, ldo/ldo2/ldaux of 8 elements");
+    CE_CHECK_ARG(lda >= K && ldb >= K && ldo >= N, "ce_gemm_nt_fp8: leading dimension smaller than the row");
+    NTArgs a;
+    a.A = (const bf16_t*)A8; a.lda = lda; a.B = (const bf16_t*)B8; a.ldb = ldb;
+    a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid; a.ldr = ldr;
+    a.out = out; a.ldo = ldo; a.out2 = (bf16_t*)out2; a.ldo2 = ldo2; a.aux = (const bf16_t*)aux; a.ldaux = ldaux;
+    a.sa = sa; a.sb = sb;
+    a.tiles_m = a.tiles_n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case CE_EPI_BF16: return launch_nt8<CE_EPI_BF16>(a, s);
+        case CE_EPI_BIAS_BF16:
+            CE_CHECK_ARG(bias, "ce_gemm_nt_fp8: bias epilogue without bias");
+            return launch_nt8<CE_EPI_BIAS_BF16>(a, s);
+        case CE_EPI_BIAS_RESID_F32:
+            CE_CHECK_ARG(bias && resid && ldr >= N && ldr % 4 == 0, "ce_gemm_nt_fp8: residual epilogue needs bias+resid");
+            return launch_nt8<CE_EPI_BIAS_RESID_F32>(a, s);
+        case CE_EPI_BIAS_GELU:
+            CE_CHECK_ARG(bias && out2 && ldo2 >= N, "ce_gemm_nt_fp8: gelu epilogue needs bias+out2");
+            return launch_nt8<CE_EPI_BIAS_GELU>(a, s);
+        case CE_EPI_GELUGRAD_BF16:
+            CE_CHECK_ARG(aux && ldaux >= N, "ce_gemm_nt_fp8: gelu-grad epilogue needs aux");
+            return launch_nt8<CE_EPI_GELUGRAD_BF16>(a, s);
+        default: CE_CHECK_ARG(false, "ce_gemm_nt_fp8: epilogue %d is not built for the fp8 path", epilogue);
+    }
+    return 0;
+}

@@ -76,6 +76,8 @@ struct Layout {
     bf16_t *dxb[2], *dxb2[2], *da[2], *dqkv[2];   // two sets (block parity): the side-stream wgrad of block l reads its
                                                   // set while block l-1 already fills the other one
     bf16_t *dh, *d_o;
+    uint8_t* q8;      // fp8 path: the quantised A operand of the GEMM being issued (rows x 4 width bytes) ...
+    float* q8s;       // ... and its per-row scales
     // compact [batch, .] buffers of the pruned last block
     float *xs_in, *xs_mid, *dxs_mid, *means, *rstds;
     bf16_t *os, *h2s, *as, *gs, *dxbs, *dxb2s, *das, *dhs, *dos;
@@ -110,6 +112,8 @@ void carve(const ce_tower_desc* d, int batch, size_t rows, void* ws, Layout& L) 
     }
     L.dh = c.take<bf16_t>(M * w);
     L.d_o = c.take<bf16_t>(M * w);
+    L.q8 = d->fp8 ? c.take<uint8_t>(M * 4 * w) : nullptr;
+    L.q8s = d->fp8 ? c.take<float>(M) : nullptr;
     const size_t Bn = (size_t)batch;
     L.xs_in = c.take<float>(Bn * w); L.xs_mid = c.take<float>(Bn * w); L.dxs_mid = c.take<float>(Bn * w);
     L.means = c.take<float>(Bn); L.rstds = c.take<float>(Bn);
@@ -140,6 +144,20 @@ int check_desc(const ce_tower_desc* d, int batch) {
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// One Linear-layer GEMM of the block, C = A . W^T (+ epilogue): bf16 (ce_gemm_nt), or -- `use8` -- A quantised per row to
+// e4m3 into the layout's scratch and multiplied with the e4m3 copy of the weight (ce_gemm_nt_fp8).  Shapes the fp8
+// kernel does not take (K not a multiple of 128, K > 4096) stay on bf16.
+int linear(bool use8, const Layout& L, const void* A, long lda, const void* W, const void* W8, const float* S8, int M,
+           int N, int K, int epi, const float* bias, const float* resid, long ldr, void* out, long ldo, void* out2,
+           long ldo2, const void* aux, long ldaux, void* stream) {
+    if (use8 && W8 && S8 && K % 128 == 0 && K <= 4096) {
+        TRY(ce_quant_rows_fp8(A, lda, L.q8, K, L.q8s, M, K, stream));
+        return ce_gemm_nt_fp8(L.q8, K, L.q8s, W8, K, S8, M, N, K, epi, bias, resid, ldr, out, ldo, out2, ldo2, aux, ldaux,
+                              stream);
+    }
+    return ce_gemm_nt(A, lda, W, K, M, N, K, epi, bias, resid, ldr, out, ldo, out2, ldo2, aux, ldaux, stream);
+}
+
 }  // namespace
 
 extern "C" size_t ce_tower_workspace_bytes(const ce_tower_desc* d, int batch) {
@@ -157,13 +175,14 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, int rows, con
     Layout L;
     carve(d, batch, rows, workspace, L);
     const int M = rows, w = d->width;
+    const bool f8 = (d->fp8 & 1) != 0;
     const float* x = x0;
     for (int l = 0; l < d->layers; ++l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
         float* xo = (l + 1 < d->layers) ? s.x_out : x_out;
         TRY(ce_layernorm_fwd(x, w, nullptr, p.ln1_w, p.ln1_b, s.h1, w, 0, s.mean1, s.rstd1, M, w, 1e-5f, stream));
-        TRY(ce_gemm_nt(s.h1, w, p.w_qkv, w, M, 3 * w, w, CE_EPI_BIAS_BF16, p.b_qkv, nullptr, 0, s.qkv, 3 * w, nullptr, 0,
+        TRY(linear(f8, L, s.h1, w, p.w_qkv, p.w8_qkv, p.s8_qkv, M, 3 * w, w, CE_EPI_BIAS_BF16, p.b_qkv, nullptr, 0, s.qkv, 3 * w, nullptr, 0,
                        nullptr, 0, stream));
         TRY(ce_attention_fwd(s.qkv, 3 * w, s.o, w, s.lse, cu_seqlens, batch, d->tokens, d->heads, d->causal, stream));
         if (sel_rows && l + 1 == d->layers) {
@@ -172,21 +191,21 @@ extern "C" int ce_tower_forward(const ce_tower_desc* d, int batch, int rows, con
             const int Bn = batch;
             TRY(ce_copy_rows(s.o, w * 2L, sel_rows, L.os, w * 2L, nullptr, Bn, w * 2, stream));
             TRY(ce_copy_rows(x, w * 4L, sel_rows, L.xs_in, w * 4L, nullptr, Bn, w * 4, stream));
-            TRY(ce_gemm_nt(L.os, w, p.w_out, w, Bn, w, w, CE_EPI_BIAS_RESID_F32, p.b_out, L.xs_in, w, L.xs_mid, w, nullptr,
+            TRY(linear(f8, L, L.os, w, p.w_out, p.w8_out, p.s8_out, Bn, w, w, CE_EPI_BIAS_RESID_F32, p.b_out, L.xs_in, w, L.xs_mid, w, nullptr,
                            0, nullptr, 0, stream));
             TRY(ce_layernorm_fwd(L.xs_mid, w, nullptr, p.ln2_w, p.ln2_b, L.h2s, w, 0, L.means, L.rstds, Bn, w, 1e-5f, stream));
-            TRY(ce_gemm_nt(L.h2s, w, p.w_fc, w, Bn, 4 * w, w, CE_EPI_BIAS_GELU, p.b_fc, nullptr, 0, L.as, 4 * w, L.gs, 4 * w,
+            TRY(linear(f8, L, L.h2s, w, p.w_fc, p.w8_fc, p.s8_fc, Bn, 4 * w, w, CE_EPI_BIAS_GELU, p.b_fc, nullptr, 0, L.as, 4 * w, L.gs, 4 * w,
                            nullptr, 0, stream));
-            TRY(ce_gemm_nt(L.gs, 4 * w, p.w_proj, 4 * w, Bn, w, 4 * w, CE_EPI_BIAS_RESID_F32, p.b_proj, L.xs_mid, w, x_out, w,
+            TRY(linear(f8, L, L.gs, 4 * w, p.w_proj, p.w8_proj, p.s8_proj, Bn, w, 4 * w, CE_EPI_BIAS_RESID_F32, p.b_proj, L.xs_mid, w, x_out, w,
                            nullptr, 0, nullptr, 0, stream));
             break;
         }
-        TRY(ce_gemm_nt(s.o, w, p.w_out, w, M, w, w, CE_EPI_BIAS_RESID_F32, p.b_out, x, w, s.x_mid, w, nullptr, 0, nullptr,
+        TRY(linear(f8, L, s.o, w, p.w_out, p.w8_out, p.s8_out, M, w, w, CE_EPI_BIAS_RESID_F32, p.b_out, x, w, s.x_mid, w, nullptr, 0, nullptr,
                        0, stream));
         TRY(ce_layernorm_fwd(s.x_mid, w, nullptr, p.ln2_w, p.ln2_b, s.h2, w, 0, s.mean2, s.rstd2, M, w, 1e-5f, stream));
-        TRY(ce_gemm_nt(s.h2, w, p.w_fc, w, M, 4 * w, w, CE_EPI_BIAS_GELU, p.b_fc, nullptr, 0, s.a, 4 * w, s.g, 4 * w,
+        TRY(linear(f8, L, s.h2, w, p.w_fc, p.w8_fc, p.s8_fc, M, 4 * w, w, CE_EPI_BIAS_GELU, p.b_fc, nullptr, 0, s.a, 4 * w, s.g, 4 * w,
                        nullptr, 0, stream));
-        TRY(ce_gemm_nt(s.g, 4 * w, p.w_proj, 4 * w, M, w, 4 * w, CE_EPI_BIAS_RESID_F32, p.b_proj, s.x_mid, w, xo, w,
+        TRY(linear(f8, L, s.g, 4 * w, p.w_proj, p.w8_proj, p.s8_proj, M, w, 4 * w, CE_EPI_BIAS_RESID_F32, p.b_proj, s.x_mid, w, xo, w,
                        nullptr, 0, nullptr, 0, stream));
         x = xo;
     }
@@ -210,6 +229,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
     Layout L;
     carve(d, batch, rows, workspace, L);
     const int M = rows, w = d->width;
+    const bool b8 = (d->fp8 & 2) != 0;
     // Per block l (buffer set q = l & 1): dxb_a = bf16 gradient at the block output (operand of mlp.c_proj's
     // dgrad/wgrad, written by block l+1's ln_1 backward), dxb_b = bf16 gradient at x_mid (attn.out_proj), da,
     // dqkv.  They stay alive until the block's four weight gradients have run as ONE grouped launch on the side
@@ -238,15 +258,15 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         BlockStash& s = L.blk[l];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         TRY(ce_cast_bf16(dx_sel, L.dxbs, (long)Bn * w, stream));
-        TRY(ce_gemm_nt(L.dxbs, w, p.wt_proj, w, Bn, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.das, 4 * w, nullptr,
+        TRY(linear(b8, L, L.dxbs, w, p.wt_proj, p.wt8_proj, p.st8_proj, Bn, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, L.das, 4 * w, nullptr,
                        0, L.as, 4 * w, stream));
         TRY(ce_colsum_bf16(L.dxbs, w, p.g_b_proj, Bn, w, stream));
-        TRY(ce_gemm_nt(L.das, 4 * w, p.wt_fc, 4 * w, Bn, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dhs, w, nullptr, 0,
+        TRY(linear(b8, L, L.das, 4 * w, p.wt_fc, p.wt8_fc, p.st8_fc, Bn, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dhs, w, nullptr, 0,
                        nullptr, 0, stream));
         TRY(ce_colsum_bf16(L.das, 4 * w, p.g_b_fc, Bn, 4 * w, stream));
         TRY(ce_layernorm_bwd(L.dhs, w, 0, L.xs_mid, w, nullptr, L.means, L.rstds, p.ln2_w, dx_sel, L.dxs_mid, w, L.dxb2s, w,
                              p.g_ln2_w, p.g_ln2_b, p.g_b_out, Bn, w, stream));
-        TRY(ce_gemm_nt(L.dxb2s, w, p.wt_out, w, Bn, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.dos, w, nullptr, 0, nullptr, 0,
+        TRY(linear(b8, L, L.dxb2s, w, p.wt_out, p.wt8_out, p.st8_out, Bn, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.dos, w, nullptr, 0, nullptr, 0,
                        stream));
         // attention sees dO only on the selected rows
         if (hipMemsetAsync(L.d_o, 0, (size_t)M * w * 2, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
@@ -267,7 +287,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         }
         TRY(ce_gemm_tn(L.dqkv[q], 3 * w, s.h1, w, M, 3 * w, w, p.g_w_qkv, w, 0, wstream));
         mark_done(l);
-        TRY(ce_gemm_nt(L.dqkv[q], 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+        TRY(linear(b8, L, L.dqkv[q], 3 * w, p.wt_qkv, p.wt8_qkv, p.st8_qkv, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));
         // residual path: dx = scatter(dx at x_mid of the selected rows), then + ln_1 backward
         if (hipMemsetAsync(dx, 0, (size_t)M * w * 4, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
@@ -285,17 +305,17 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         bf16_t *dxb_a = L.dxb[q], *dxb_b = L.dxb2[q], *da = L.da[q], *dqkv = L.dqkv[q];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         // ---- mlp.c_proj : x_out = x_mid + g Wp^T + bp ----
-        TRY(ce_gemm_nt(dxb_a, w, p.wt_proj, w, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, da, 4 * w, p.g_b_fc,
+        TRY(linear(b8, L, dxb_a, w, p.wt_proj, p.wt8_proj, p.st8_proj, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, da, 4 * w, p.g_b_fc,
                        4 * w, s.a, 4 * w, stream));                               // da = (dx Wp) * gelu'(a); g_b_fc += colsum(da)
         if (l == last) TRY(ce_colsum_bf16(dxb_a, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
         // ---- mlp.c_fc : a = h2 Wf^T + bf ----
-        TRY(ce_gemm_nt(da, 4 * w, p.wt_fc, 4 * w, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+        TRY(linear(b8, L, da, 4 * w, p.wt_fc, p.wt8_fc, p.st8_fc, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh2 = da Wf
         // ---- ln_2 (+ residual); also the column sums of dx = attn.out_proj bias gradient ----
         TRY(ce_layernorm_bwd(L.dh, w, 0, s.x_mid, w, nullptr, s.mean2, s.rstd2, p.ln2_w, dx, dx, w, dxb_b, w, p.g_ln2_w,
                              p.g_ln2_b, p.g_b_out, M, w, stream));
         // ---- attn.out_proj : x_mid = x_in + o Wo^T + bo ----
-        TRY(ce_gemm_nt(dxb_b, w, p.wt_out, w, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
+        TRY(linear(b8, L, dxb_b, w, p.wt_out, p.wt8_out, p.st8_out, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
                        stream));                                                  // d_o = dx Wo
         // ---- attention core ----
         TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, p.g_b_qkv, cu_seqlens, batch, d->tokens, d->heads,
@@ -315,7 +335,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         }
         mark_done(l);
         // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
-        TRY(ce_gemm_nt(dqkv, 3 * w, p.wt_qkv, 3 * w, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
+        TRY(linear(b8, L, dqkv, 3 * w, p.wt_qkv, p.wt8_qkv, p.st8_qkv, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh1 = dqkv Wqkv
         // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient.  It writes the
         // other buffer set's dxb, which wgrad(l+1) may still be reading ----

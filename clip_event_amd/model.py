@@ -37,12 +37,14 @@ class _BlockParams(ctypes.Structure):
         "ln1_w", "ln1_b", "ln2_w", "ln2_b", "b_qkv", "b_out", "b_fc", "b_proj",
         "w_qkv", "w_out", "w_fc", "w_proj", "wt_qkv", "wt_out", "wt_fc", "wt_proj",
         "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b", "g_b_qkv", "g_b_out", "g_b_fc", "g_b_proj",
-        "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj")]
+        "g_w_qkv", "g_w_out", "g_w_fc", "g_w_proj",
+        "w8_qkv", "w8_out", "w8_fc", "w8_proj", "s8_qkv", "s8_out", "s8_fc", "s8_proj",
+        "wt8_qkv", "wt8_out", "wt8_fc", "wt8_proj", "st8_qkv", "st8_out", "st8_fc", "st8_proj")]
 
 
 class _TowerDesc(ctypes.Structure):
     _fields_ = [("layers", c_int), ("width", c_int), ("heads", c_int), ("tokens", c_int), ("causal", c_int),
-                ("blocks", ctypes.POINTER(_BlockParams))]
+                ("blocks", ctypes.POINTER(_BlockParams)), ("fp8", c_int)]
 
 
 # --------------------------------------------------------------------------- parameter holders
@@ -207,13 +209,17 @@ class CLIP(nn.Module):
         # text tower on the live tokens only (rows after a caption's EOT are dead under the causal mask); results
         # are unchanged, see functional.text_packing.  CE_TEXT_PACK=0 keeps the dense [n, 77] layout.
         self.pack_text = os.environ.get("CE_TEXT_PACK", "1") != "0"
+        # fp8 (OCP e4m3) operand path for the blocks' Linear GEMMs (BASELINE config 5; which tensors may go to low
+        # precision follows convert_weights, model_clip.py:554-575): bit 0 = forward GEMMs, bit 1 = input-gradient
+        # GEMMs.  fp32 masters, bf16 copies (weight gradients) and everything else are unchanged.  Off by default.
+        self.fp8 = int(os.environ.get("CE_FP8", "0"))
 
     # ---- copy / pickle: the device-side tables (ctypes descriptors, workspace pool, streams, operand copies) are
     # rebuilt lazily by _prepare(); only the parameters and the plain attributes travel --------------------------
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
                 "_tjobs_n", "_tjobs_tiles", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
-                "_side_streams", "_main_stream", "_pack_cache", "grad_sync")
+                "_side_streams", "_main_stream", "_pack_cache", "grad_sync", "_w8", "_fp8_fresh")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -463,19 +469,59 @@ class CLIP(nn.Module):
                 f.g_ln1_w, f.g_ln1_b, f.g_ln2_w, f.g_ln2_b = G("ln_1.weight"), G("ln_1.bias"), G("ln_2.weight"), G("ln_2.bias")
                 f.g_b_qkv, f.g_b_out = G("attn.in_proj_bias"), G("attn.out_proj.bias")
                 f.g_b_fc, f.g_b_proj = G("mlp.c_fc.bias"), G("mlp.c_proj.bias")
-            d = _TowerDesc(tr.layers, tr.width, tr.heads, tokens, 1 if causal else 0, arr)
+            d = _TowerDesc(tr.layers, tr.width, tr.heads, tokens, 1 if causal else 0, arr, 0)
             d._keep = arr
             return d
 
         self._vdesc = desc("visual.transformer.", self.visual.transformer, self.visual.patch_num ** 2 + 1, False)
         self._tdesc = desc("transformer.", self.transformer, self.context_length, True)
         lib().ce_tower_workspace_bytes.restype = ctypes.c_size_t
+        self._w8 = None
+        self._fp8_fresh = False
+
+    def _build_fp8_tables(self):
+        """e4m3 copies of the blocks' GEMM weights, one fp32 scale per row: straight [out,in] (scale per output
+        channel) for the forward, transposed [in,out] (scale per input channel) for the input-gradient GEMMs."""
+        dev = self._flat.device
+        self._w8 = {}
+        for prefix, d in (("visual.transformer.", self._vdesc), ("transformer.", self._tdesc)):
+            for i in range(d.layers):
+                f = d.blocks[i]
+                for short, name in (("qkv", "attn.in_proj_weight"), ("out", "attn.out_proj.weight"),
+                                    ("fc", "mlp.c_fc.weight"), ("proj", "mlp.c_proj.weight")):
+                    n = f"{prefix}resblocks.{i}.{name}"
+                    o, k = self._pmap[n].shape
+                    t = (torch.empty(o, k, dtype=torch.uint8, device=dev), torch.empty(o, dtype=torch.float32, device=dev),
+                         torch.empty(k, o, dtype=torch.uint8, device=dev), torch.empty(k, dtype=torch.float32, device=dev))
+                    self._w8[n] = t
+                    setattr(f, "w8_" + short, t[0].data_ptr())
+                    setattr(f, "s8_" + short, t[1].data_ptr())
+                    setattr(f, "wt8_" + short, t[2].data_ptr())
+                    setattr(f, "st8_" + short, t[3].data_ptr())
+        self._fp8_fresh = False
+
+    def _refresh_fp8(self):
+        """Requantise from the bf16 operand copies (they have just been refreshed from the masters)."""
+        if self._w8 is None:
+            self._build_fp8_tables()
+        cl, s = lib(), stream()
+        for n, (w8, s8, w8t, s8t) in self._w8.items():
+            o, k = w8.shape
+            check(cl.ce_quant_rows_fp8(ptr(self._w16[n]), c_long(k), ptr(w8), c_long(k), ptr(s8), c_int(o), c_int(k), s),
+                  "ce_quant_rows_fp8(w)")
+            if self.fp8 & 2:
+                check(cl.ce_quant_rows_fp8(ptr(self._w16t[n]), c_long(o), ptr(w8t), c_long(o), ptr(s8t), c_int(k), c_int(o), s),
+                      "ce_quant_rows_fp8(wt)")
+        self._fp8_fresh = True
 
     def refresh_operands(self, force: bool = False):
         """Re-cast the bf16 GEMM operands from the fp32 masters when a master changed
         (in-place optimiser update, ``load_state_dict``)."""
         vers = tuple(self._pmap[n]._version for n in self._cast_list)
+        self._vdesc.fp8 = self._tdesc.fp8 = int(self.fp8)
         if not force and vers == self._versions:
+            if self.fp8 and not self._fp8_fresh:
+                self._refresh_fp8()
             return
         s = stream()
         cl = lib()
@@ -491,6 +537,9 @@ class CLIP(nn.Module):
                                        c_long(0), c_int(self.vision_width), c_int(self._kp_real), s), "ce_cast_transpose(conv1)")
         self._mirror_fresh = False
         self._versions = vers
+        self._fp8_fresh = False
+        if self.fp8:
+            self._refresh_fp8()
 
     def mark_operands_stale(self, mirror_fresh: bool = False):
         """``mirror_fresh``: the caller (fused Adam) has already written the bf16 mirror of the new masters,

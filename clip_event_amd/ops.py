@@ -102,3 +102,29 @@ def probe_tr16(image: torch.Tensor, byte_off: torch.Tensor) -> torch.Tensor:
     out = torch.empty(64, 4, device=image.device, dtype=torch.int16)
     check(lib().ce_probe_tr16(ptr(image), c_int(image.numel()), ptr(byte_off), ptr(out), stream()), "ce_probe_tr16")
     return out
+
+
+def quant_rows_fp8(x: torch.Tensor):
+    """(q uint8 [M,K] of e4m3 bytes, scale f32 [M]) = per-row quantisation of a bf16 matrix (ce_quant_rows_fp8)."""
+    assert x.dtype == torch.bfloat16 and x.is_cuda and x.stride(1) == 1
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().ce_quant_rows_fp8(ptr(x), c_long(x.stride(0)), ptr(q), c_long(K), ptr(scale), c_int(M), c_int(K), stream()),
+          "ce_quant_rows_fp8")
+    return q, scale
+
+
+def gemm_nt_fp8(a8, sa, b8, sb, epilogue: int, *, bias=None, resid=None, aux=None, colsum=None):
+    """out[M,N] = sa[m] sb[n] (a8[M,K] @ b8[N,K]^T) with a fused epilogue (ce_gemm_nt_fp8)."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    f32_out = epilogue == L.EPI_BIAS_RESID_F32
+    out = torch.empty(M, N, device=a8.device, dtype=torch.float32 if f32_out else torch.bfloat16)
+    out2 = torch.empty_like(out) if epilogue == L.EPI_BIAS_GELU else colsum
+    check(lib().ce_gemm_nt_fp8(ptr(a8), c_long(a8.stride(0)), ptr(sa), ptr(b8), c_long(b8.stride(0)), ptr(sb), c_int(M),
+                               c_int(N), c_int(K), c_int(epilogue), ptr(bias), ptr(resid),
+                               c_long(resid.stride(0) if resid is not None else 0), ptr(out), c_long(out.stride(0)),
+                               ptr(out2), c_long(out2.stride(0) if epilogue == L.EPI_BIAS_GELU else 0), ptr(aux),
+                               c_long(aux.stride(0) if aux is not None else 0), stream()), "ce_gemm_nt_fp8")
+    return (out, out2) if epilogue == L.EPI_BIAS_GELU else out

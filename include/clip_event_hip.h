@@ -76,6 +76,19 @@ int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int
 int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const void* const* Q, const long* ldq, int M,
                        const int* Nn, const int* Kk, float* const* out, const long* ldo, int splits, void* stream);
 
+/* ---- fp8 (OCP e4m3) operand path (gemm_fp8.hip; BASELINE config 5, tensors as convert_weights model_clip.py:554-575) ----
+ * q[r,:] (e4m3 bytes) = x[r,:] (bf16) * 2^e_r with the power of two that puts the row's amax into (224, 448],
+ * scale[r] = 2^-e_r (1 for an all-zero row); exact scaling, so the bytes are reproducible anywhere; K <= 4096 */
+int ce_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, void* stream);
+/* C[m,n] = sa[m] * sb[n] * sum_k A8[m,k] * B8[n,k] (e4m3 operands, one fp32 scale per row of each, fp32 accumulate on
+ * v_mfma_scale_f32_16x16x128_f8f6f4) with the fused epilogues of ce_gemm_nt (BF16, BIAS_BF16, BIAS_RESID_F32, BIAS_GELU,
+ * GELUGRAD_BF16).  K % 128 == 0; lda/ldb in bytes (= elements). */
+int ce_gemm_nt_fp8(const void* A8, long lda, const float* sa, const void* B8, long ldb, const float* sb, int M, int N,
+                   int K, int epilogue, const float* bias, const float* resid, long ldr, void* out, long ldo, void* out2,
+                   long ldo2, const void* aux, long ldaux, void* stream);
+/* tuning hook (tools/ only): 0 auto, 4/5/6/8 = tile height (x32 rows) of the 256-column kernel, 105 = 160x128 tile */
+void ce_gemm_nt_fp8_tune(int variant);
+
 /* y = LayerNorm(x[rows[r]] or x[r]) over D columns, fp32 statistics (eps inside the sqrt).
  * y is bf16 (out_f32=0: the next GEMM's operand) or fp32 (ln_pre: the residual stream).
  * Writes mean/rstd [M] for the backward.  Replaces LayerNorm.forward, model_clip.py:157-163. */
@@ -210,11 +223,20 @@ typedef struct ce_block_params {
     float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b;
     float *g_b_qkv, *g_b_out, *g_b_fc, *g_b_proj;
     float *g_w_qkv, *g_w_out, *g_w_fc, *g_w_proj;
+    /* fp8 path (read only when ce_tower_desc.fp8 != 0): e4m3 copies of w_* ([out,in], scale per out row) and of
+     * wt_* ([in,out], scale per in row), see ce_quant_rows_fp8 */
+    const void *w8_qkv, *w8_out, *w8_fc, *w8_proj;
+    const float *s8_qkv, *s8_out, *s8_fc, *s8_proj;
+    const void *wt8_qkv, *wt8_out, *wt8_fc, *wt8_proj;
+    const float *st8_qkv, *st8_out, *st8_fc, *st8_proj;
 } ce_block_params;
 
 typedef struct ce_tower_desc {
     int layers, width, heads, tokens, causal;
     const ce_block_params* blocks; /* host array [layers] of device pointers */
+    int fp8;                       /* bit 0: forward Linear GEMMs on the fp8 path, bit 1: the input-gradient GEMMs too
+                                    * (activations / gradients are quantised per row on the fly; weight gradients,
+                                    * attention, LayerNorm and the residual stream are unchanged) */
 } ce_tower_desc;
 
 /* bytes of activation stash + backward scratch for `batch` samples */

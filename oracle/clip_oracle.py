@@ -8,7 +8,8 @@ state-dict names; every function cites the reference
 Activations use the batch-first NLD layout; the reference's LND permutes
 (model_clip.py:247-249, :404-408) are layout-only and do not change values.
 
-``bf16=True`` emulates the rounding points of the HIP path (bf16 GEMM
+``bf16="fp8"`` additionally quantises both operands of the blocks' Linear GEMMs to e4m3 with per-row scales
+(BASELINE config 5; ``_linear``).  ``bf16=True`` emulates the rounding points of the HIP path (bf16 GEMM
 operands, fp32 accumulation, fp32 residual stream, fp32 LayerNorm/softmax) so
 that the forward of the device path can be checked with a tight tolerance.
 With ``bf16=False`` this is the reference's fp32 arithmetic, pinned by
@@ -166,6 +167,34 @@ def _r(x: torch.Tensor, bf16: bool) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if bf16 else x
 
 
+def _q8(x: torch.Tensor):
+    """Per-row e4m3 quantisation of the bf16-rounded values, as ``ce_quant_rows_fp8`` does it: the power-of-two
+    scale that puts the row's amax into (224, 448] (amax = m 2^k, m in [0.5,1): inv = 2^(9-k), or 2^(8-k) when
+    m > 0.875), q = RNE_e4m3(x * inv); all-zero rows keep scale 1.  Returns (q as fp32, scale [...,1])."""
+    xb = x.detach().to(torch.bfloat16).to(torch.float32)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    m, k = torch.frexp(amax)
+    e = 9 - k - (m > 0.875).to(k.dtype)
+    live = amax >= 2.0 ** -100
+    one = torch.ones_like(amax)
+    inv = torch.where(live, torch.ldexp(one, e), one)
+    scale = torch.where(live, torch.ldexp(one, -e), one)
+    return (xb * inv).to(torch.float8_e4m3fn).to(torch.float32), scale
+
+
+def _linear(x: torch.Tensor, w: torch.Tensor, mode) -> torch.Tensor:
+    """x @ w^T of a block's Linear layer at the HIP path's rounding points.  ``mode`` False: fp32 (the reference);
+    True: bf16 operands; "fp8": the BASELINE config 5 path -- both operands e4m3 with per-row scales in the forward
+    VALUE, while the gradient flows as on the bf16 path (the HIP backward multiplies with the bf16 copies)."""
+    y = _r(x, bool(mode)) @ _r(w, bool(mode)).t()
+    if mode == "fp8":
+        qx, sx = _q8(x)
+        qw, sw = _q8(w)
+        y8 = (qx @ qw.t()) * sx * sw.reshape(-1)
+        y = y + (y8 - y).detach()
+    return y
+
+
 def layer_norm(x, w, b, eps: float = 1e-5):
     """``LayerNorm`` fp32-internal (model_clip.py:157-163); eps = nn default 1e-5."""
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps)
@@ -189,7 +218,7 @@ def attention(x_ln, p, prefix: str, heads: int, mask: Optional[torch.Tensor], bf
     B, L, D = x_ln.shape
     hd = D // heads
     w_in, b_in = p[prefix + "attn.in_proj_weight"], p[prefix + "attn.in_proj_bias"]
-    qkv = _r(_r(x_ln, bf16) @ _r(w_in, bf16).t() + b_in, bf16)          # [B,L,3D]
+    qkv = _r(_linear(x_ln, w_in, bf16) + b_in, bf16)                    # [B,L,3D]
     q, k, v = qkv.split(D, dim=-1)
     q = q.view(B, L, heads, hd).transpose(1, 2)
     k = k.view(B, L, heads, hd).transpose(1, 2)
@@ -200,7 +229,7 @@ def attention(x_ln, p, prefix: str, heads: int, mask: Optional[torch.Tensor], bf
     a = torch.softmax(s, dim=-1)
     o = _r(_r(a, bf16) @ v, bf16)                                       # [B,H,L,hd]
     o = o.transpose(1, 2).reshape(B, L, D)
-    return o @ _r(p[prefix + "attn.out_proj.weight"], bf16).t() + p[prefix + "attn.out_proj.bias"]
+    return _linear(o, p[prefix + "attn.out_proj.weight"], bf16) + p[prefix + "attn.out_proj.bias"]
 
 
 def residual_block(x, p, prefix: str, heads: int, mask, bf16: bool = False):
@@ -208,9 +237,9 @@ def residual_block(x, p, prefix: str, heads: int, mask, bf16: bool = False):
     x = x + attention(layer_norm(x, p[prefix + "ln_1.weight"], p[prefix + "ln_1.bias"]),
                       p, prefix, heads, mask, bf16)
     h = _r(layer_norm(x, p[prefix + "ln_2.weight"], p[prefix + "ln_2.bias"]), bf16)
-    a = h @ _r(p[prefix + "mlp.c_fc.weight"], bf16).t() + p[prefix + "mlp.c_fc.bias"]
+    a = _linear(h, p[prefix + "mlp.c_fc.weight"], bf16) + p[prefix + "mlp.c_fc.bias"]
     g = _r(quick_gelu(a), bf16)
-    x = x + (g @ _r(p[prefix + "mlp.c_proj.weight"], bf16).t() + p[prefix + "mlp.c_proj.bias"])
+    x = x + (_linear(g, p[prefix + "mlp.c_proj.weight"], bf16) + p[prefix + "mlp.c_proj.bias"])
     return x
 
 

@@ -287,3 +287,98 @@ def test_multi_transpose_table():
     torch.cuda.synchronize()
     for a, b in zip(srcs, dsts):
         assert torch.equal(b.view(torch.int16).cpu(), a.t().contiguous().view(torch.int16).cpu()), tuple(a.shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) operand path, BASELINE config 5
+
+def _q8_ref(x_bf16: torch.Tensor):
+    """torch restatement of ce_quant_rows_fp8 (== oracle.clip_oracle._q8): bytes, scales, dequantisable values."""
+    xb = x_bf16.float()
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    m, k = torch.frexp(amax)
+    e = 9 - k - (m > 0.875).to(k.dtype)
+    live = amax >= 2.0 ** -100
+    one = torch.ones_like(amax)
+    inv = torch.where(live, torch.ldexp(one, e), one)
+    q = (xb * inv).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), torch.where(live, torch.ldexp(one, -e), one).flatten(), q.float()
+
+
+@pytest.mark.parametrize("M,K", [(7, 128), (300, 768), (64, 1024), (33, 4096), (5, 72)])
+def test_quant_rows_fp8_is_bit_exact(M, K):
+    """Integer / byte work: the e4m3 bytes and the fp32 scales equal torch's float8_e4m3fn conversion exactly
+    (OCP e4m3fn on gfx950, round to nearest even), including an all-zero row and a row with one huge outlier."""
+    from clip_event_amd import ops
+    rng = np.random.default_rng(M + K)
+    x = _randn(rng, M, K) * torch.exp(_randn(rng, M, 1) * 3)
+    x[0] = 0.0
+    x[-1, 3] = 6.0e4
+    xb = x.to(torch.bfloat16)
+    q_ref, s_ref, _ = _q8_ref(xb)
+    q, s = ops.quant_rows_fp8(xb.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(s.cpu(), s_ref)
+    bad = (q.cpu() != q_ref).nonzero()
+    detail = [(int(r), int(c), float(xb[r, c]), float(s_ref[r]), int(q.cpu()[r, c]), int(q_ref[r, c])) for r, c in bad[:8]]
+    assert len(bad) == 0, f"{len(bad)} of {M * K} e4m3 bytes differ: (row, col, x, scale, hip byte, torch byte) {detail}"
+    amax_q = (q_ref.view(torch.float8_e4m3fn).float().abs().amax(dim=-1))
+    assert bool(((amax_q >= 224) | (xb.float().abs().amax(dim=-1) == 0)).all()) and float(amax_q.max()) <= 448
+
+
+F8_SHAPES = [(128, 128, 128), (400, 768, 512), (77, 512, 2048), (1000, 2304, 768), (130, 136, 256), (2000, 1024, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", F8_SHAPES)
+def test_gemm_nt_fp8(M, N, K):
+    """The fp8 MFMA product on exactly representable operands against fp32 PyTorch on the SAME dequantised values:
+    products of two e4m3 numbers are exact in fp32, so only the summation order differs (1e-5 relative before the
+    bf16 store; the bf16 output is then compared at bf16 rounding)."""
+    from clip_event_amd import ops, _lib as L
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    qa, sa, fa = _q8_ref(a)
+    qb, sb, fb = _q8_ref(b)
+    ref = (fa @ fb.t()) * sa[:, None] * sb[None, :]
+    bias = _randn(rng, N)
+    resid = _randn(rng, M, N)
+    A8, SA, B8, SB = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV)
+    o = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_RESID_F32, bias=bias.to(DEV), resid=resid.to(DEV)).cpu()
+    torch.cuda.synchronize()
+    err, rel = _report(f"fp8 nt {M}x{N}x{K} bias+resid f32", o, ref + bias + resid)
+    assert rel < 1e-5
+    o16 = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BF16).float().cpu()
+    assert _report("fp8 nt bf16", o16, ref.to(torch.bfloat16).float())[1] < 3e-3
+    # and against the UNquantised product: what e4m3 costs (reported, loosely bounded)
+    full = a.float() @ b.float().t()
+    qerr = ((ref - full).norm() / full.norm()).item()
+    print(f"   e4m3 quantisation error of the product vs bf16 operands: rel_l2={qerr:.3e}")
+    assert qerr < 6e-2
+
+
+def test_gemm_nt_fp8_epilogues():
+    from clip_event_amd import ops, _lib as L
+    M, N, K = 400, 512, 256
+    rng = np.random.default_rng(5)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    qa, sa, fa = _q8_ref(a)
+    qb, sb, fb = _q8_ref(b)
+    acc = (fa @ fb.t()) * sa[:, None] * sb[None, :]
+    bias = _randn(rng, N)
+    aux = _randn(rng, M, N).to(torch.bfloat16)
+    A8, SA, B8, SB = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV)
+    o = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_BF16, bias=bias.to(DEV)).float().cpu()
+    assert _report("fp8 bias_bf16", o, (acc + bias).to(torch.bfloat16).float())[1] < 3e-3
+    pre, g = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+    h = acc + bias
+    assert _report("fp8 gelu pre", pre.float().cpu(), h)[1] < 3e-3
+    assert _report("fp8 gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
+    colsum = torch.zeros(N, device=DEV)
+    o = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV), colsum=colsum).float().cpu()
+    x = aux.float()
+    s = torch.sigmoid(1.702 * x)
+    want = acc * (s * (1 + 1.702 * x * (1 - s)))
+    assert _report("fp8 gelugrad", o, want)[1] < 3e-3
+    assert _report("fp8 gelugrad colsum", colsum.cpu(), want.sum(0))[1] < 2e-3

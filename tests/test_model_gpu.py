@@ -777,3 +777,59 @@ def test_tower_backward_ranges_with_side_stream_wgrad():
     assert _rel(got, ref) < 1e-5
     for key, (a, end, snap) in rec.snap.items():
         assert _rel(snap, ref[a:end]) < 1e-5, key
+
+
+@pytest.mark.parametrize("bits", [1, 3])
+def test_fp8_weight_path_against_oracle_with_the_same_quantisation_points(bits):
+    """BASELINE config 5's fp8 path at the patch-14 tiny geometry (model_clip.py:554-575 names the tensors a
+    low-precision path may touch: the blocks' Linear weights).  bit 0: forward GEMMs on e4m3 operands with per-row
+    scales -- features against the oracle run with the SAME quantisation points: cosine >= 0.998 (an e4m3 rounding
+    decision flips on a bf16-level difference of its input -- summation order, the attention core's bf16 rounding
+    points -- and a flip is a 6-12 % step of that element, so not the 0.9995 of the bf16 test; measured 0.9997 image /
+    0.9987 text), and closer to the fp8 oracle than to the bf16 one; logits |d| <= 0.8 at scale 14.3 and loss
+    |d| <= 0.25 (six samples, no averaging: the same flips),
+    gradients against the oracle's (value from the fp8 forward, derivative through the bf16 copies, exactly what
+    the HIP backward does) cosine >= 0.98 (measured 0.995).  bits 0+1: the input-gradient GEMMs quantise the gradients per
+    row as well: gradient cosine >= 0.97 against the same oracle (measured 0.990), total gradient norm within 10 %."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.losses import CriterionContrastive
+    cfg = O.ClipConfig(64, 56, 3, 128, 14, 20, 512, 128, 2, 3)
+    m, sd = _mk(cfg, 13)
+    m.fp8 = bits
+    B = 6
+    img = S.synthetic_images(B, cfg.image_resolution, seed=71)
+    txt = S.synthetic_tokens(B, cfg.context_length, cfg.vocab_size, seed=72, min_len=2)
+    yi, yt, ip = O.build_labels(B, 1, 0, True)
+    with torch.no_grad():
+        fi = m.encode_image(img.to(DEV)).cpu()
+        ft = m.encode_text(txt.to(DEV)).cpu()
+        fi_grid = m.encode_image(img.to(DEV), use_grid=True).cpu()
+    fi_o = O.encode_image(sd, cfg, img, bf16="fp8")
+    ft_o = O.encode_text(sd, cfg, txt, bf16="fp8")
+    fi_b = O.encode_image(sd, cfg, img, bf16=True)
+    print(f"[fp8={bits}] image features cosine vs fp8 oracle {_cos(fi, fi_o):.6f} (vs the bf16 oracle {_cos(fi, fi_b):.6f}); "
+          f"text {_cos(ft, ft_o):.6f}; grid {_cos(fi_grid, O.encode_image(sd, cfg, img, use_grid=True, bf16='fp8')):.6f}")
+    assert _cos(fi, fi_o) > 0.998 and _cos(ft, ft_o) > 0.998
+    assert _cos(fi, fi_o) > _cos(fi, fi_b) - 1e-4          # it really is the fp8 computation
+    li, lt = m(img.to(DEV), txt.to(DEV))
+    ld = CriterionContrastive("ce")(li, lt, yi.to(DEV), yt.to(DEV), index_pos=ip.to(DEV))
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    ld_o, g_o, _ = O.loss_and_grads(sd, cfg, img, txt, yi, yt, ip, True, bf16="fp8")
+    print(f"[fp8={bits}] loss_i {float(ld['loss_i']):.4f} (oracle {float(ld_o['loss_i']):.4f})")
+    li_o = O.clip_forward(sd, cfg, img, txt, True, "fp8")[0]
+    print(f"[fp8={bits}] max |dlogit| {float((li.detach().cpu() - li_o).abs().max()):.4f}")
+    assert float((li.detach().cpu() - li_o).abs().max()) < 0.8
+    assert abs(float(ld["loss_i"]) - float(ld_o["loss_i"])) < 0.25 and abs(float(ld["loss_t"]) - float(ld_o["loss_t"])) < 0.25
+    worst, rels = _grad_report(m, g_o, f"fp8={bits}")
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    gn_o = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g_o.values() if g is not None)))
+    print(f"[fp8={bits}] total grad norm {gn:.4f} (oracle {gn_o:.4f})")
+    assert worst[0] > (0.98 if bits == 1 else 0.97)
+    assert abs(gn - gn_o) < 0.1 * gn_o
+    # the switch is live: turning it off gives the bf16 path again
+    m.fp8 = 0
+    with torch.no_grad():
+        fi0 = m.encode_image(img.to(DEV)).cpu()
+    assert _cos(fi0, fi_b) > 0.9995

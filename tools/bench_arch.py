@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Train-step timing of other CLIP geometries on the HIP path (BASELINE config 5's ViT-L/14 at 336 px in bf16,
-ViT-B/16).  Not the headline metric: bench.py stays on ViT-B/32."""
+"""Train-step timing of other CLIP geometries on the HIP path (BASELINE config 5's ViT-L/14 at 336 px, ViT-B/16), in
+bf16 or with the fp8 operand path (--fp8 / --fp8=3).  Not the headline metric: bench.py stays on ViT-B/32.
+
+    python tools/bench_arch.py vit_l14_336 [batch] [--fp8[=bits]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,13 +16,19 @@ ARCH = {   # default batch, nominal fwd+bwd FLOP per pair
     "vit_b16": (128, 3 * 2 * (17.58e9 + 2.9798e9)),
     "vit_l14_336": (32, 1185.7e9),
 }
-name = sys.argv[1] if len(sys.argv) > 1 else "vit_l14_336"
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+fp8 = 0
+for a in sys.argv[1:]:
+    if a.startswith("--fp8"):            # --fp8 (forward GEMMs) / --fp8=3 (forward + input-gradient GEMMs)
+        fp8 = int(a.split("=")[1]) if "=" in a else 1
+name = argv[0] if argv else "vit_l14_336"
 B, flop_pair = ARCH[name]
-if len(sys.argv) > 2:
-    B = int(sys.argv[2])
+if len(argv) > 1:
+    B = int(argv[1])
 dev = torch.device("cuda", 0)
 t0 = time.time()
 model = S.synthetic_model(name, seed=0).to(dev)
+model.fp8 = fp8
 print(f"{name}: built in {time.time()-t0:.1f}s, {sum(p.numel() for p in model.parameters())/1e6:.0f} M parameters, "
       f"{model.visual.patch_num ** 2 + 1} image tokens", flush=True)
 crit = CriterionContrastive("ce")
@@ -38,7 +46,7 @@ for _ in range(N):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 loss = float(sum(v.detach() for v in ld.values()))
-print(f"{name} B={B}: {dt*1e3:.1f} ms/step = {B/dt:,.0f} pairs/s, loss {loss:.4f}, "
+print(f"{name} B={B} fp8={fp8}: {dt*1e3:.1f} ms/step = {B/dt:,.0f} pairs/s, loss {loss:.4f}, "
       f"{B/dt*flop_pair/2.5e15*100:.1f} % of bf16 peak on nominal FLOPs")
 
 # per-class breakdown (single stream so that the HIP-event intervals are not stretched by overlap)
