@@ -189,8 +189,6 @@ def main():
     B = args.batch
     model = S.synthetic_model("vit_b32", seed=0).to(dev)         # same weights on every rank
     model.tower_streams = not args.single_stream
-    if args.single_stream:
-        lib().ce_tower_wgrad_stream(0)
     crit = CriterionContrastive("ce")
     opt = FusedAdam(model, lr=1e-6, weight_decay=0.0, max_norm=1.0)    # README.md:189-191 defaults
     sync = D.GradSync(model) if ((W > 1 or force) and os.environ.get("CE_NO_GRAD_SYNC", "0") != "1") else None
@@ -266,7 +264,6 @@ def main():
         # kernels are timed in isolation: both towers on ONE stream for this pass (in the timed region they
         # overlap on two streams, which would stretch every per-kernel duration)
         model.tower_streams = False
-        cl.ce_tower_wgrad_stream(0)
         for _ in range(2):
             step()
         torch.cuda.synchronize()

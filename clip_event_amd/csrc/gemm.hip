@@ -239,6 +239,40 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- epilogue operand prefetch.  The fp32 residual tile (BIAS_RESID_F32: 32 B per output row-slot and lane) and the
+    // bf16 pre-activation tile (GELUGRAD_BF16: 16 B) used to be read inside the epilogue, serial with the K loop; they
+    // are now loaded into registers during the LAST NPF K iterations (a few loads per iteration, issued ahead of that
+    // iteration's LDS-DMA so they are the older entries of the in-order vmcnt queue) and are resident when the
+    // accumulators come out of the LDS transpose.  Row-slot (mh, it) = output row m0 + wm*16*TM + mh*64 + it*8 + e_r.
+    constexpr bool PF_RESID = EPI == CE_EPI_BIAS_RESID_F32 && TM <= 5;
+    constexpr bool PF_AUX = EPI == CE_EPI_GELUGRAD_BF16 && TM <= 6;
+    constexpr bool PF = PF_RESID || PF_AUX;
+    constexpr int SLOTS = ((TM + 3) / 4 - 1) * 8 + ((TM % 4 == 0) ? 8 : (TM % 4) * 2);
+    constexpr int NPF = 4;
+    constexpr int PER = (SLOTS + NPF - 1) / NPF;
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;          // epilogue map: row e_r (+8 per slot), 8 columns
+    const int gn = n0 + wn * 64 + e_c;
+    f32x4 rp[PF_RESID ? SLOTS : 1][2];
+    u32x4 ap[PF_AUX ? SLOTS : 1];
+    auto prefetch_group = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int slot = g * PER + q;
+            if (slot < SLOTS) {
+                const int m = m0 + wm * (TM * 16) + (slot >> 3) * 64 + (slot & 7) * 8 + e_r;
+                const bool ok = m < p.M && gn < p.N;
+                if constexpr (PF_RESID) {
+                    const float* r = p.resid + (long)m * p.ldr + gn;
+                    rp[slot][0] = ok ? *reinterpret_cast<const f32x4*>(r) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    rp[slot][1] = ok ? *reinterpret_cast<const f32x4*>(r + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if constexpr (PF_AUX) {
+                    ap[slot] = ok ? *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + gn) : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+    };
+
     const int nk = p.K / N2_BK;
     stage(0, 0);
     __syncthreads();     // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
@@ -247,7 +281,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
     const int fa_base = (wm * (TM * 16) + f_row) * 128;
     const int fb_base = N2_TILE_BYTES + (wn * 64 + f_row) * 128;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    auto k_iter = [&](int kt) __attribute__((always_inline)) {
         const int cur = kt & 1;
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* st = smem + cur * N2_STAGE_BYTES;
@@ -259,8 +293,6 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
             for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
 #pragma unroll
             for (int mh = 0; mh * 4 < TM; ++mh) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 bf16x8 af[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -277,6 +309,20 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
             }
         }
         __syncthreads();
+    };
+    if constexpr (!PF) {
+        for (int kt = 0; kt < nk; ++kt) k_iter(kt);
+    } else if (nk >= NPF) {
+        for (int kt = 0; kt < nk - NPF; ++kt) k_iter(kt);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            prefetch_group(j);
+            k_iter(nk - NPF + j);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) prefetch_group(j);
+        for (int kt = 0; kt < nk; ++kt) k_iter(kt);
     }
 
     // ---- epilogue through LDS: each wave transposes its 128x64 fp32 sub-tile in two 64x64 halves
@@ -285,8 +331,6 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
     // (the loop's last barrier guarantees every wave is done with the operand stages)
     constexpr int EROW = 272;
     char* ebuf = smem + wave * (64 * EROW);
-    const int e_r = lane >> 3, e_c = (lane & 7) * 8;          // row-phase map: row e_r (+8/iter), 8 columns
-    const int gn = n0 + wn * 64 + e_c;
     f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
@@ -318,7 +362,26 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
             if (m < p.M && gn < p.N) {
                 v0 += bias0;
                 v1 += bias1;
-                nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+                if constexpr (PF_RESID) {
+                    const int slot = mh * 8 + it;
+                    v0 += rp[slot][0];
+                    v1 += rp[slot][1];
+                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + gn;
+                    *reinterpret_cast<f32x4*>(o) = v0;
+                    *reinterpret_cast<f32x4*>(o + 4) = v1;
+                } else if constexpr (PF_AUX) {
+                    const u32x4 a = ap[mh * 8 + it];
+                    f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
+                                v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
+                    f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
+                                v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
+                    cs0 += r0;
+                    cs1 += r1;
+                    u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
+                } else {
+                    nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+                }
             }
         }
     }
@@ -757,8 +820,8 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p) {
 // separate launches.
 struct TNGroup {
     int count, splits, m_per_split, M;
-    int tile_end[4];
-    TNArgs prob[4];
+    int tile_end[CE_TN_MAX_GROUP];
+    TNArgs prob[CE_TN_MAX_GROUP];
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
@@ -877,6 +940,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
 
         const int ek = k0 + wk * 64 + (lane & 31);
         const int en = n0 + wn * 64 + 4 * (lane >> 5);
+        // (a sole writer -- splits == 1 -- could add by plain read-modify-write; measured SLOWER than the no-return
+        // float atomics: the 64 dependent cold reads per lane are a latency tail, the atomics are fire-and-forget)
+        constexpr bool sole = false;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -886,10 +952,147 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
-                    if (n < p.Nn) atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
+                    if (n < p.Nn) {
+                        float* o = p.out + (long)n * p.ldo + k;
+                        if (sole) *o += acc[nt][kt][r];
+                        else atomicAdd(o, acc[nt][kt][r]);
+                    }
                 }
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN kernel v3: 256(n) x 256(k) output tile, 16 waves (4 x 4, each 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 as in v2), ONE
+// workgroup per CU.  rocprofv3 SQ counters of v2 in the step (profiles/r02_pmc_sq_*.txt): 51 % of the wave-cycles parked
+// on s_waitcnt / barriers, matrix pipe busy 29 % -- the 128x128 tiles pull 2.8 GB through L2 per launch (~20 TB/s) with
+// at most 64 KB in flight per CU, i.e. the loop waits for operand delivery.  A 256x256 tile halves the operand bytes per
+// FLOP and gives every DMA twice as many matrix-cycles to land; the LDS images, the DMA map, the swizzle and the
+// transposed fragment reads are v2's (a stage = four [64][128] images: P0 P1 Q0 Q1, 64 KB; two stages).
+// Needs Nn, Kk multiples of 256 (every ViT-B/32 / ViT-L/14 block weight is); other shapes stay on v2.
+// A launch with a single M split owns every output element exactly once, so it adds with a plain read-modify-write
+// (6 TB/s class) instead of memory-side float atomics (1.3 TB/s chip-wide, MI355X_MICROARCH.md "Global float atomics").
+// ------------------------------------------------------------------------------------------
+constexpr int T3_IMG_BYTES = TN_BM * 256;                // 16 KiB: 64 rows x 128 columns
+constexpr int T3_STAGE_BYTES = 4 * T3_IMG_BYTES;         // 64 KiB
+constexpr int T3_LDS_BYTES = 2 * T3_STAGE_BYTES;         // 128 KiB
+
+__global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wk = wave & 3;
+
+    const int m_tiles = (grp.M + TN_BM - 1) / TN_BM;
+    const int mps = grp.m_per_split / TN_BM;
+    const int s_r = lane >> 4;
+    const int s_chunk = (lane & 15) ^ (s_r << 2);
+    const int g = lane >> 4, li = lane & 15;
+    const int t_row = 8 * (g >> 1) + (li >> 2);
+    const int t_sw = (li >> 2) << 2;
+    const int t_cb = 2 * (g & 1) + ((li & 3) >> 1);
+    int offP[2], offQ[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        offP[t] = (wn >> 1) * T3_IMG_BYTES + t_row * 256 + ((((wn & 1) * 8 + t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
+        offQ[t] = (2 + (wk >> 1)) * T3_IMG_BYTES + t_row * 256 + ((((wk & 1) * 8 + t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
+    }
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    int tile = lb / grp.splits;
+    const int mt0 = (lb - tile * grp.splits) * mps;
+    const int mt1 = min(m_tiles, mt0 + mps);
+    if (mt0 >= mt1) return;  // uniform per block
+    int pi = 0;
+    while (pi + 1 < grp.count && tile >= grp.tile_end[pi]) ++pi;   // block-uniform
+    if (pi > 0) tile -= grp.tile_end[pi - 1];
+    const TNArgs& p = grp.prob[pi];
+    int tn, tk;
+    {
+        constexpr int BNB = 2, BKB = 2;      // 2x2 blocks of 256^2 tiles = the panel sharing of v2's 4x4 blocks
+        const int br = tile / (BNB * p.tiles_k);
+        const int r0 = br * BNB, rows_b = min(BNB, p.tiles_n - r0);
+        const int t1 = tile - br * BNB * p.tiles_k;
+        const int bc = t1 / (rows_b * BKB);
+        const int c0 = bc * BKB, cols_b = min(BKB, p.tiles_k - c0);
+        const int t2 = t1 - bc * rows_b * BKB;
+        tn = r0 + t2 / cols_b;
+        tk = c0 + t2 % cols_b;
+    }
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int ms = mt0 * TN_BM;
+    const int rows = min(grp.M, mt1 * TN_BM) - ms;
+
+    // DMA: wave w fills image w>>2 (P0 P1 Q0 Q1), instructions (w&3)*4 .. +3 of its 16 (4 rows x 256 B each)
+    const int img = wave >> 2;
+    const bool isP = img < 2;
+    const long ld = isP ? p.ldp : p.ldq;
+    const bf16_t* src = isP ? p.P : p.Q;
+    const int col0 = (isP ? n0 : k0) + 128 * (img & 1);
+    const u32x4 rsrc = make_rsrc_words(src + (long)ms * ld, (uint32_t)((long)rows * ld * 2));
+    uint32_t vo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = ((wave & 3) * 4 + j) * 4 + s_r;
+        vo[j] = (uint32_t)(row * ld * 2 + (col0 + s_chunk * 8) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + img * T3_IMG_BYTES + (wave & 3) * 4096;
+    auto stage = [&](int st, int mt) {
+        const uint32_t d = lds0 + st * T3_STAGE_BYTES;
+        const uint32_t mb = (uint32_t)((long)mt * TN_BM * ld * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16_bounds(rsrc, d + j * 1024, vo[j] + mb);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+    }
+
+    const int nmt = mt1 - mt0;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int mt = 0; mt < nmt; ++mt) {
+        const int cur = mt & 1;
+        if (mt + 1 < nmt) stage(cur ^ 1, mt + 1);
+        const char* st = smem + cur * T3_STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 pf[2], qf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                pf[t] = tr_frag2(st + offP[t] + s * 16 * 256);
+                qf[t] = tr_frag2(st + offQ[t] + s * 16 * 256);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (this wave's DMA)
+        __syncthreads();
+    }
+
+    const int ek = k0 + wk * 64 + (lane & 31);
+    const int en = n0 + wn * 64 + 4 * (lane >> 5);
+    constexpr bool sole = false;             // see gemm_tn2_kernel: read-modify-write measured slower than atomics
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k = ek + kt * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+                float* o = p.out + (long)n * p.ldo + k;
+                if (sole) *o += acc[nt][kt][r];
+                else atomicAdd(o, acc[nt][kt][r]);
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1120,14 +1323,17 @@ extern "C" int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq,
 extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const void* const* Q,
                                   const long* ldq, int M, const int* Nn, const int* Kk, float* const* out,
                                   const long* ldo, int splits, void* stream) {
-    CE_CHECK_ARG(count >= 1 && count <= 4 && M > 0, "ce_gemm_tn_grouped: 1..4 problems, M > 0");
+    CE_CHECK_ARG(count >= 1 && count <= CE_TN_MAX_GROUP && M > 0, "ce_gemm_tn_grouped: 1..%d problems, M > 0", CE_TN_MAX_GROUP);
     static std::once_flag attr_set;
-    static int variant = 2;   // CE_GEMM_TN=1 forces the register-staged v1 kernel (one launch per problem)
+    static int variant = 2;   // CE_GEMM_TN: 1 = register-staged v1 kernel (one launch per problem), 2 = 128x128 v2 (default),
+                              // 3 = 256x256 v3 where the shapes allow (faster on cache-warm operands, slower in the step)
     std::call_once(attr_set, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TN_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             T2_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            T3_LDS_BYTES);
         const char* e = getenv("CE_GEMM_TN");
         if (e) variant = atoi(e);
     });
@@ -1154,7 +1360,7 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         if (ldp[i] > ldmax) ldmax = ldp[i];
         if (ldq[i] > ldmax) ldmax = ldq[i];
     }
-    for (int i = count; i < 4; ++i) g.tile_end[i] = tiles;
+    for (int i = count; i < CE_TN_MAX_GROUP; ++i) g.tile_end[i] = tiles;
     const int m_tiles = ce_div_up(M, TN_BM);
     CE_CHECK_ARG((long)M * ldmax * 2 < (1L << 32), "ce_gemm_tn: operand exceeds 4 GiB");
     if (variant == 1) {
@@ -1172,7 +1378,47 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         CE_LAUNCH_CHECK();
         return 0;
     }
-    // v2: one resident round (at most 2 workgroups per CU = 512 slots), never a ragged second round
+    // v3 (256x256 tiles, one workgroup per CU) when every problem is a multiple of 256 both ways and the contraction is
+    // long enough to amortise the 64 KB prologue
+    bool can3 = variant == 3 && M >= 2048;
+    for (int i = 0; i < count; ++i) can3 = can3 && Nn[i] % 256 == 0 && Kk[i] % 256 == 0;
+    if (can3) {
+        int tiles3 = 0;
+        for (int i = 0; i < count; ++i) {
+            TNArgs& a = g.prob[i];
+            a.tiles_n = Nn[i] / 256; a.tiles_k = Kk[i] / 256;
+            tiles3 += a.tiles_n * a.tiles_k;
+            g.tile_end[i] = tiles3;
+        }
+        for (int i = count; i < CE_TN_MAX_GROUP; ++i) g.tile_end[i] = tiles3;
+        static int force_splits = getenv("CE_TN3_SPLITS") ? atoi(getenv("CE_TN3_SPLITS")) : 0;
+        // M split by a cost model fitted to tools/bench_tn_group.py (us): a workgroup spends 1.7 per 64-row contraction
+        // tile + 3 of prologue; rounds of 256 workgroups; only the LAST round's epilogue is exposed -- 0.20 per tile with
+        // float atomics (256 KB at 1.3 TB/s chip-wide), 0.105 as a plain read-modify-write when nothing is split
+        auto cost = [&](int sp) {
+            const long wgs = (long)tiles3 * sp;
+            const long rounds = (wgs + 255) / 256;
+            const long tail = wgs - (rounds - 1) * 256;
+            return rounds * (ce_div_up(m_tiles, sp) * 1.7 + 3.0) + tail * (sp == 1 ? 0.105 : 0.20);
+        };
+        int sp = 1;
+        if (splits > 0) sp = splits;
+        else if (force_splits > 0) sp = force_splits;
+        else {
+            double best = cost(1);
+            for (int c = 2; c <= 16 && c <= m_tiles; ++c)
+                if (cost(c) < best) { best = cost(c); sp = c; }
+        }
+        if (sp > m_tiles) sp = m_tiles;
+        if (sp < 1) sp = 1;
+        g.m_per_split = ce_div_up(m_tiles, sp) * TN_BM;
+        g.splits = ce_div_up(M, g.m_per_split);
+        CeProfScope prof(CE_PROF_GEMM_TN, flops, bytes, s);
+        hipLaunchKernelGGL(gemm_tn3_kernel, dim3((unsigned)(tiles3 * g.splits)), dim3(1024), T3_LDS_BYTES, s, g);
+        CE_LAUNCH_CHECK();
+        return 0;
+    }
+    // v2: one resident round (at most 2 workgroups per CU = 512 slots), never a ragged second round of SPLIT tiles
     if (splits <= 0) splits = 512 / tiles;
     if (splits > m_tiles) splits = m_tiles;
     if (splits < 1) splits = 1;

@@ -37,38 +37,54 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float norm = sqrtf(*sumsq);
         coef = fminf(1.0f, max_norm / (norm + 1e-6f));
     }
-    const long stride = gridDim.x * 1024L;
-    for (long i = blockIdx.x * 1024L + threadIdx.x * 4; i < n; i += stride) {
-        if (i + 3 < n) {
-            f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
-            f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * coef;
-            f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
-            f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
-            if (wd != 0.f) gv += pv * wd;
-            mv = mv * b1 + gv * (1.0f - b1);
-            vv = vv * b2 + gv * gv * (1.0f - b2);
+    // two 16-byte chunks per lane and iteration, all eight loads issued before the first use: the pass is pure streaming
+    // (16 B read + 14 B written per parameter) and wants as many bytes in flight as the registers allow
+    const long stride = gridDim.x * 2048L;
+    for (long i0 = blockIdx.x * 2048L + threadIdx.x * 4; i0 < n; i0 += stride) {
+        const long i1 = i0 + 1024;
+        if (i1 + 3 < n) {
+            f32x4 pv[2], gv[2], mv[2], vv[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-                pv[e] -= (lr / bc1) * (mv[e] / denom);
+            for (int u = 0; u < 2; ++u) {
+                const long i = u ? i1 : i0;
+                pv[u] = *reinterpret_cast<f32x4*>(p + i);
+                gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+                mv[u] = *reinterpret_cast<f32x4*>(m + i);
+                vv[u] = *reinterpret_cast<f32x4*>(v + i);
             }
-            *reinterpret_cast<f32x4*>(p + i) = pv;
-            if (p16) {
-                u32x2 pk = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
-                *reinterpret_cast<u32x2*>(p16 + i) = pk;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long i = u ? i1 : i0;
+                gv[u] = gv[u] * coef;
+                if (wd != 0.f) gv[u] += pv[u] * wd;
+                mv[u] = mv[u] * b1 + gv[u] * (1.0f - b1);
+                vv[u] = vv[u] * b2 + gv[u] * gv[u] * (1.0f - b2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float denom = sqrtf(vv[u][e]) / bc2_sqrt + eps;
+                    pv[u][e] -= (lr / bc1) * (mv[u][e] / denom);
+                }
+                *reinterpret_cast<f32x4*>(p + i) = pv[u];
+                if (p16) {
+                    u32x2 pk = {pack_bf2(pv[u][0], pv[u][1]), pack_bf2(pv[u][2], pv[u][3])};
+                    *reinterpret_cast<u32x2*>(p16 + i) = pk;
+                }
+                *reinterpret_cast<f32x4*>(m + i) = mv[u];
+                *reinterpret_cast<f32x4*>(v + i) = vv[u];
             }
-            *reinterpret_cast<f32x4*>(m + i) = mv;
-            *reinterpret_cast<f32x4*>(v + i) = vv;
         } else {
-            for (long k = i; k < n; ++k) {
-                float gk = g[k] * coef;
-                if (wd != 0.f) gk += p[k] * wd;
-                const float mk = m[k] * b1 + gk * (1.0f - b1);
-                const float vk = v[k] * b2 + gk * gk * (1.0f - b2);
-                p[k] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2_sqrt + eps));
-                m[k] = mk;
-                v[k] = vk;
-                if (p16) p16[k] = f2bf(p[k]);
+            for (int u = 0; u < 2; ++u) {
+                const long ib = u ? i1 : i0;
+                for (long k = ib; k < n && k < ib + 4; ++k) {
+                    float gk = g[k] * coef;
+                    if (wd != 0.f) gk += p[k] * wd;
+                    const float mk = m[k] * b1 + gk * (1.0f - b1);
+                    const float vk = v[k] * b2 + gk * gk * (1.0f - b2);
+                    p[k] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+                    m[k] = mk;
+                    v[k] = vk;
+                    if (p16) p16[k] = f2bf(p[k]);
+                }
             }
         }
     }
@@ -157,7 +173,7 @@ extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, void* 
     CE_CHECK_ARG(n > 0 && step >= 1, "ce_adam_step: need n>0 and step>=1");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
-    long blocks = (n + 1023) / 1024;
+    long blocks = (n + 2047) / 2048;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, sumsq,
                        max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);

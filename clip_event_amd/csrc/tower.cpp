@@ -17,38 +17,13 @@
 
 namespace {
 
-// Weight gradients are off the critical path of the backward chain (nothing downstream of a block reads them),
-// so each tower CAN issue them on a SIDE stream (off by default, CE_WGRAD_STREAM=1): they overlap the memory-bound kernels of the dgrad chain
-// (LayerNorm / attention backward, where the MFMA units idle) instead of serialising with them.
-// One context per caller stream, created lazily: a non-blocking side stream and two events per block.
-struct SideCtx {
-    hipStream_t side = nullptr;
-    hipEvent_t ready[64];
-    hipEvent_t done[64];
-    bool ok = false;
-};
-std::mutex g_side_mu;
-std::map<hipStream_t, SideCtx*> g_side;
-int g_wgrad_stream = -1;
-
-SideCtx* side_ctx(hipStream_t main) {
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    if (g_wgrad_stream < 0) {
-        const char* e = getenv("CE_WGRAD_STREAM");
-        g_wgrad_stream = e ? atoi(e) : 0;   // measured: with the two towers already on two streams the extra
-                                            // concurrency costs 3 % (cache / CU contention); kept as an option
-    }
-    if (!g_wgrad_stream) return nullptr;
-    auto it = g_side.find(main);
-    if (it != g_side.end()) return it->second->ok ? it->second : nullptr;
-    SideCtx* c = new SideCtx();
-    c->ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 64 && c->ok; ++i)
-        c->ok = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) == hipSuccess;
-    g_side[main] = c;
-    return c->ok ? c : nullptr;
-}
+// Weight gradients are off the critical path of the backward chain (nothing downstream of a block reads them), so the
+// backward DEFERS them: the four problems of a block are queued and several consecutive blocks' queues go out as ONE
+// grouped launch (ce_gemm_tn_grouped): several rounds of unsplit tiles, so each round's atomic epilogue (memory-side
+// float atomics run at 1.3 TB/s chip-wide: a 10-20 % tail of a one-round launch) overlaps the next round's contraction.  The gradient operands (bf16
+// dY buffers) of the queued blocks stay alive in a ring of WG_SETS buffer sets.
+constexpr int WG_MAX_BLOCKS = 5;            // blocks per grouped launch (x 4 problems <= CE_TN_MAX_GROUP)
+constexpr int WG_SETS = WG_MAX_BLOCKS + 1;  // a block writes its own set and the next block's dxb
 
 struct Carver {
     char* base;
@@ -73,8 +48,9 @@ struct BlockStash {
 struct Layout {
     static constexpr int MAX_LAYERS = 64;
     BlockStash blk[MAX_LAYERS];
-    bf16_t *dxb[2], *dxb2[2], *da[2], *dqkv[2];   // two sets (block parity): the side-stream wgrad of block l reads its
-                                                  // set while block l-1 already fills the other one
+    bf16_t *dxb[WG_SETS], *dxb2[WG_SETS], *da[WG_SETS], *dqkv[WG_SETS];   // ring of gradient-operand sets (block l uses
+                                                                           // set l % WG_SETS): alive until the queued
+                                                                           // weight gradients of the block have launched
     bf16_t *dh, *d_o;
     uint8_t* q8;      // fp8 path: the quantised A operand of the GEMM being issued (rows x 4 width bytes) ...
     float* q8s;       // ... and its per-row scales
@@ -104,7 +80,7 @@ void carve(const ce_tower_desc* d, int batch, size_t rows, void* ws, Layout& L) 
         s.rstd2 = c.take<float>(M);
         s.lse = c.take<float>((size_t)batch * d->heads * d->tokens);
     }
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < WG_SETS; ++q) {
         L.dxb[q] = c.take<bf16_t>(M * w);
         L.dxb2[q] = c.take<bf16_t>(M * w);
         L.da[q] = c.take<bf16_t>(M * 4 * w);
@@ -230,22 +206,38 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
     carve(d, batch, rows, workspace, L);
     const int M = rows, w = d->width;
     const bool b8 = (d->fp8 & 2) != 0;
-    // Per block l (buffer set q = l & 1): dxb_a = bf16 gradient at the block output (operand of mlp.c_proj's
-    // dgrad/wgrad, written by block l+1's ln_1 backward), dxb_b = bf16 gradient at x_mid (attn.out_proj), da,
-    // dqkv.  They stay alive until the block's four weight gradients have run as ONE grouped launch on the side
-    // stream; block l-2 (same set) may only overwrite them after that launch has finished.
+    // Per block l (buffer set q = l % WG_SETS): dxb_a = bf16 gradient at the block output (operand of mlp.c_proj's
+    // dgrad/wgrad, written by block l+1's ln_1 backward), dxb_b = bf16 gradient at x_mid (attn.out_proj), da, dqkv.
+    // They stay alive until the block's four queued weight gradients have gone out in a grouped launch (same
+    // stream, so a later block may reuse a set as soon as that launch is ENQUEUED; the queue never holds more than
+    // WG_MAX_BLOCKS blocks and a block only writes sets l and l-1).
     hipStream_t ms = (hipStream_t)stream;
-    SideCtx* sc = side_ctx(ms);
-    void* wstream = sc ? (void*)sc->side : stream;
     const int last = d->layers - 1;
-    auto mark_ready = [&](int l) {       // everything wgrad(l) reads has been enqueued on the main stream
-        if (sc) { hipEventRecord(sc->ready[l], ms); hipStreamWaitEvent(sc->side, sc->ready[l], 0); }
+    // blocks per grouped launch: WG_MAX_BLOCKS.  Measured in the ViT-B/32 step (128x128-tile kernel, float atomics):
+    // 1 block per launch 4.14 ms of weight-gradient time per step, 2: 3.97, 4: 4.01, 5: 3.83 -- a long unsplit multi-round
+    // launch overlaps every round's atomic epilogue with the next round's contraction and pays one ramp-up
+    int group = WG_MAX_BLOCKS;
+    static const int force_group = getenv("CE_WGRAD_GROUP") ? atoi(getenv("CE_WGRAD_GROUP")) : 0;
+    if (force_group >= 1 && force_group <= WG_MAX_BLOCKS) group = force_group;
+    struct Pending {
+        const void* P[CE_TN_MAX_GROUP]; long ldp[CE_TN_MAX_GROUP];
+        const void* Q[CE_TN_MAX_GROUP]; long ldq[CE_TN_MAX_GROUP];
+        int Nn[CE_TN_MAX_GROUP], Kk[CE_TN_MAX_GROUP];
+        float* out[CE_TN_MAX_GROUP]; long ldo[CE_TN_MAX_GROUP];
+        int count = 0, blocks = 0;
+    } pend;
+    auto queue = [&](const void* P, long ldp, const void* Q, long ldq, int Nn, int Kk, float* out, long ldo) {
+        const int i = pend.count++;
+        pend.P[i] = P; pend.ldp[i] = ldp; pend.Q[i] = Q; pend.ldq[i] = ldq;
+        pend.Nn[i] = Nn; pend.Kk[i] = Kk; pend.out[i] = out; pend.ldo[i] = ldo;
     };
-    auto mark_done = [&](int l) {
-        if (sc) hipEventRecord(sc->done[l], sc->side);
-    };
-    auto wait_done = [&](int l) {        // main stream: do not overwrite set (l&1) before wgrad(l) has read it
-        if (sc && l >= 0 && l <= last) hipStreamWaitEvent(ms, sc->done[l], 0);
+    auto flush = [&]() -> int {
+        if (pend.count == 0) return 0;
+        const int rc = ce_gemm_tn_grouped(pend.count, pend.P, pend.ldp, pend.Q, pend.ldq, M, pend.Nn, pend.Kk, pend.out,
+                                          pend.ldo, 0, stream);
+        pend.count = 0;
+        pend.blocks = 0;
+        return rc;
     };
     int top = layer_hi;
     if (layer_hi < last) {
@@ -253,7 +245,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
     } else if (sel_rows) {
         // ---- pruned last block (see ce_tower_forward): compact rows through the MLP and the out-projection ----
         CE_CHECK_ARG(dx_sel, "ce_tower_backward: pruned mode needs dx_sel");
-        const int l = top, Bn = batch, q = l & 1;
+        const int l = top, Bn = batch, q = l % WG_SETS;
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
@@ -273,7 +265,6 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         TRY(ce_copy_rows(L.dos, w * 2L, nullptr, L.d_o, w * 2L, sel_rows, Bn, w * 2, stream));
         TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, L.dqkv[q], 3 * w, p.g_b_qkv, cu_seqlens, batch, d->tokens, d->heads,
                              d->causal, stream));
-        mark_ready(l);
         {
             const void* P[3] = {L.dxbs, L.das, L.dxb2s};
             const long ldp[3] = {w, 4L * w, w};
@@ -283,25 +274,24 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
             const int Kk[3] = {4 * w, w, w};
             float* out[3] = {p.g_w_proj, p.g_w_fc, p.g_w_out};
             const long ldo[3] = {4L * w, w, w};
-            TRY(ce_gemm_tn_grouped(3, P, ldp, Q, ldq, Bn, Nn, Kk, out, ldo, 0, wstream));
+            TRY(ce_gemm_tn_grouped(3, P, ldp, Q, ldq, Bn, Nn, Kk, out, ldo, 0, stream));
         }
-        TRY(ce_gemm_tn(L.dqkv[q], 3 * w, s.h1, w, M, 3 * w, w, p.g_w_qkv, w, 0, wstream));
-        mark_done(l);
+        queue(L.dqkv[q], 3L * w, s.h1, w, 3 * w, w, p.g_w_qkv, w);     // goes out with the next block(s)' gradients
         TRY(linear(b8, L, L.dqkv[q], 3 * w, p.wt_qkv, p.wt8_qkv, p.st8_qkv, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));
         // residual path: dx = scatter(dx at x_mid of the selected rows), then + ln_1 backward
         if (hipMemsetAsync(dx, 0, (size_t)M * w * 4, ms) != hipSuccess) { ce_set_error("tower: memset failed"); return -5; }
         TRY(ce_copy_rows(L.dxs_mid, w * 4L, nullptr, dx, w * 4L, sel_rows, Bn, w * 4, stream));
-        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[q ^ 1], w, p.g_ln1_w,
+        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[(l + WG_SETS - 1) % WG_SETS], w, p.g_ln1_w,
                              p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
         top = l - 1;
     } else {
-        TRY(ce_cast_bf16(dx, L.dxb[top & 1], (long)M * w, stream));
+        TRY(ce_cast_bf16(dx, L.dxb[top % WG_SETS], (long)M * w, stream));
     }
     for (int l = top; l >= layer_lo; --l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
-        const int q = l & 1;
+        const int q = l % WG_SETS;
         bf16_t *dxb_a = L.dxb[q], *dxb_b = L.dxb2[q], *da = L.da[q], *dqkv = L.dqkv[q];
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         // ---- mlp.c_proj : x_out = x_mid + g Wp^T + bp ----
@@ -320,38 +310,22 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         // ---- attention core ----
         TRY(ce_attention_bwd(s.qkv, 3 * w, s.o, w, L.d_o, w, s.lse, dqkv, 3 * w, p.g_b_qkv, cu_seqlens, batch, d->tokens, d->heads,
                              d->causal, stream));
-        // ---- the four weight gradients of this block, one launch, on the side stream ----
-        mark_ready(l);
-        {
-            const void* P[4] = {dxb_a, da, dxb_b, dqkv};
-            const long ldp[4] = {w, 4L * w, w, 3L * w};
-            const void* Q[4] = {s.g, s.h2, s.o, s.h1};
-            const long ldq[4] = {4L * w, w, w, w};
-            const int Nn[4] = {w, 4 * w, w, 3 * w};
-            const int Kk[4] = {4 * w, w, w, w};
-            float* out[4] = {p.g_w_proj, p.g_w_fc, p.g_w_out, p.g_w_qkv};
-            const long ldo[4] = {4L * w, w, w, w};
-            TRY(ce_gemm_tn_grouped(4, P, ldp, Q, ldq, M, Nn, Kk, out, ldo, 0, wstream));
-        }
-        mark_done(l);
+        // ---- the four weight gradients of this block: queued, launched with the neighbouring blocks' ----
+        queue(dxb_a, w, s.g, 4L * w, w, 4 * w, p.g_w_proj, 4L * w);
+        queue(da, 4L * w, s.h2, w, 4 * w, w, p.g_w_fc, w);
+        queue(dxb_b, w, s.o, w, w, w, p.g_w_out, w);
+        queue(dqkv, 3L * w, s.h1, w, 3 * w, w, p.g_w_qkv, w);
+        if (++pend.blocks >= group || pend.count + 4 > CE_TN_MAX_GROUP) TRY(flush());
         // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
         TRY(linear(b8, L, dqkv, 3 * w, p.wt_qkv, p.wt8_qkv, p.st8_qkv, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh1 = dqkv Wqkv
         // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient.  It writes the
-        // other buffer set's dxb, which wgrad(l+1) may still be reading ----
-        wait_done(l + 1);
-        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[q ^ 1], w, p.g_ln1_w,
+        // next block's dxb (set l-1) ----
+        TRY(ce_layernorm_bwd(L.dh, w, 0, x_in, w, nullptr, s.mean1, s.rstd1, p.ln1_w, dx, dx, w, L.dxb[(l + WG_SETS - 1) % WG_SETS], w, p.g_ln1_w,
                              p.g_ln1_b, (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, M, w, stream));
     }
-    // every weight-gradient launch of this call that the loop has not already waited for (block l's is waited for
-    // by block l-1's ln_1 backward): the two lowest blocks of the range.  The caller hands the gradients of
-    // blocks >= layer_lo to the all-reduce as soon as this returns.
-    wait_done(layer_lo);
-    wait_done(layer_lo + 1);
+    // the caller hands the gradients of blocks >= layer_lo to the all-reduce as soon as this returns: nothing stays queued
+    TRY(flush());
     return 0;
 }
 
-extern "C" void ce_tower_wgrad_stream(int on) {
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    g_wgrad_stream = on ? 1 : 0;
-}

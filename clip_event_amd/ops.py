@@ -31,7 +31,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, epilogue: int, *, bias=None, resid
         out2 = torch.empty_like(out)
     check(lib().ce_gemm_nt(ptr(a), c_long(a.stride(0)), ptr(b), c_long(b.stride(0)), c_int(M), c_int(N), c_int(K),
                            c_int(epilogue), ptr(bias), ptr(resid), c_long(resid.stride(0) if resid is not None else 0),
-                           ptr(out), c_long(out.stride(0)), ptr(out2), c_long(out2.stride(0) if out2 is not None else 0),
+                           ptr(out), c_long(out.stride(0)), ptr(out2),
+                           c_long(0 if out2 is None else (N if out2.dim() == 1 else out2.stride(0))),   # 1-D: GELUGRAD column sums
                            ptr(aux), c_long(aux.stride(0) if aux is not None else 0), stream()), "ce_gemm_nt")
     return (out, out2) if epilogue == L.EPI_BIAS_GELU else out
 

@@ -72,7 +72,10 @@ int ce_gemm_tn(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, 
 /* same, plus the bias gradient bias_grad[n] (f32 [Nn], nullable) += sum_m P[m,n] */
 int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int Nn, int Kk, float* out, long ldo,
                     float* bias_grad, int splits, void* stream);
-/* 1..4 weight-gradient problems sharing M in one launch (the four Linear layers of a residual block) */
+/* 1..CE_TN_MAX_GROUP weight-gradient problems sharing M in one launch (the four Linear layers of a residual block, or of
+ * several consecutive blocks: with about one resident round of tiles the launch needs no M split, and an unsplit tile is
+ * added by plain read-modify-write instead of float atomics) */
+#define CE_TN_MAX_GROUP 20
 int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const void* const* Q, const long* ldq, int M,
                        const int* Nn, const int* Kk, float* const* out, const long* ldo, int splits, void* stream);
 
@@ -282,9 +285,6 @@ int ce_ot_bwd(const float* txt, long tsb, long tsr, const float* img, long isb, 
 int ce_bbox_pool_fwd(const float* grid, long sb, long s0, long s1, const int* boxes, float* out, int nbox, int E,
                      void* stream);
 int ce_bbox_pool_bwd(const float* dout, const int* boxes, float* dgrid, int g, int nbox, int E, void* stream);
-
-/* weight gradients of the tower backward on a side stream (default off; CE_WGRAD_STREAM=1 or this call turn it on) */
-void ce_tower_wgrad_stream(int on);
 
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);

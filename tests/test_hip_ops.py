@@ -41,10 +41,13 @@ def test_gemm_nt_bf16_and_f32(M, N, K):
     assert torch.equal(out16.cpu(), out32.cpu().to(torch.bfloat16))
 
 
-def test_gemm_nt_epilogues():
+@pytest.mark.parametrize("M,N,K", [(400, 512, 256), (1100, 768, 512), (2000, 520, 256), (12800, 768, 768), (3000, 2048, 512),
+                                   (1300, 512, 192)])
+def test_gemm_nt_epilogues(M, N, K):
+    """Every fused epilogue at shapes that reach each kernel family (128^2 register-staged; 256-column LDS-DMA
+    kernels with the epilogue-operand prefetch, ragged M / N edges; K of 3 tiles = shorter than the prefetch window)."""
     from clip_event_amd import ops, _lib as L
-    M, N, K = 400, 512, 256
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + M)
     a = _randn(rng, M, K).to(torch.bfloat16)
     b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
     bias = _randn(rng, N)
@@ -62,13 +65,17 @@ def test_gemm_nt_epilogues():
     h = acc + bias
     assert _report("gelu pre", pre.float().cpu(), h)[1] < 3e-3
     assert _report("gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
-    o = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV)).float().cpu()
+    colsum = torch.zeros(N, device=DEV)
+    o = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV), out2=colsum).float().cpu()
     x = aux.float()
     s = torch.sigmoid(1.702 * x)
-    assert _report("gelugrad", o, acc * (s * (1 + 1.702 * x * (1 - s))))[1] < 3e-3
+    want = acc * (s * (1 + 1.702 * x * (1 - s)))
+    assert _report("gelugrad", o, want)[1] < 3e-3
+    assert _report("gelugrad colsum", colsum.cpu(), want.sum(0))[1] < 3e-3
 
 
-TN_SHAPES = [(64, 128, 128), (256, 256, 384), (1000, 768, 512), (77 * 8, 512, 2048), (50, 64, 72), (12800, 768, 768)]
+TN_SHAPES = [(64, 128, 128), (256, 256, 384), (1000, 768, 512), (77 * 8, 512, 2048), (50, 64, 72), (12800, 768, 768),
+             (4096, 512, 2048), (2120, 256, 256), (11137, 2048, 512)]      # the last three: the 256x256-tile kernel, ragged M
 
 
 @pytest.mark.parametrize("M,Nn,Kk", TN_SHAPES)

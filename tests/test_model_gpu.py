@@ -729,56 +729,6 @@ def test_load_state_dict_after_a_fused_adam_step():
     assert torch.equal(got[0], ref[0])
 
 
-def test_tower_backward_ranges_with_side_stream_wgrad():
-    """CE_WGRAD_STREAM=1: the weight gradients run on a side stream; when a layer range returns, every weight
-    gradient of the blocks it covers must be ordered before the caller's stream (the data-parallel exchange reads
-    them next).  Same recorder as the range test, with the side stream on."""
-    from oracle import clip_oracle as O
-    from clip_event_amd import synthetic as S
-    from clip_event_amd._lib import lib
-    from clip_event_amd.losses import CriterionContrastive
-    cfg = O.ClipConfig(64, 64, 5, 128, 32, 20, 512, 128, 2, 4)
-    m, _ = _mk(cfg, 6)
-    img = S.synthetic_images(64, cfg.image_resolution, seed=1).to(DEV)
-    txt = S.synthetic_tokens(64, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
-    yi, yt, ip = (t.to(DEV) for t in O.build_labels(64, 1, 0, True))
-    crit = CriterionContrastive("ce")
-
-    def backward():
-        m.zero_grad()
-        ld = crit(*m(img, txt), yi, yt, index_pos=ip)
-        sum(ld.values()).backward()
-        torch.cuda.synchronize()
-        return m._flat_grad.clone()
-
-    ref = backward()
-
-    class Recorder:
-        def __init__(self):
-            self.snap = {}
-
-        def layer_cuts(self, tower, layers):
-            return [c for c in (layers - 1, layers // 2, 1) if 0 < c < layers]
-
-        def __call__(self, model, tower, upto_layer=None):
-            # what a collective launched now would read: a copy enqueued on this stream, NO host synchronisation
-            a, b = model._ranges[tower]
-            end = b if upto_layer is None else model._layer_end[tower][upto_layer]
-            self.snap[(tower, upto_layer)] = (a, end, model._flat_grad[a:end].clone())
-
-    lib().ce_tower_wgrad_stream(1)
-    try:
-        rec = Recorder()
-        m.grad_sync = rec
-        got = backward()
-        m.grad_sync = None
-    finally:
-        lib().ce_tower_wgrad_stream(0)
-    assert _rel(got, ref) < 1e-5
-    for key, (a, end, snap) in rec.snap.items():
-        assert _rel(snap, ref[a:end]) < 1e-5, key
-
-
 @pytest.mark.parametrize("bits", [1, 3])
 def test_fp8_weight_path_against_oracle_with_the_same_quantisation_points(bits):
     """BASELINE config 5's fp8 path at the patch-14 tiny geometry (model_clip.py:554-575 names the tensors a
