@@ -113,7 +113,7 @@ def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected
     + WRITE_SIZE, tools/pmc_traffic.py; PMC needs its own runs, so bench.py cannot collect it live)."""
     import glob
-    prefix = {"gemm_tn": "gemm_tn2_kernel"}.get(kernel_class)
+    prefix = {"gemm_tn": "gemm_tn"}.get(kernel_class)        # gemm_tn3_kernel (or gemm_tn2_kernel): first = longest
     import re
 
     def version_key(path):          # r02_..._v10.json sorts after r02_..._v9.json, and r02 after r01

@@ -819,7 +819,7 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* p) {
 // chip with few (usually 1-2) M splits -> 4x fewer atomic bytes and 4x longer-lived workgroups than four
 // separate launches.
 struct TNGroup {
-    int count, splits, m_per_split, M;
+    int count, splits, m_per_split, M, depth;
     int tile_end[CE_TN_MAX_GROUP];
     TNArgs prob[CE_TN_MAX_GROUP];
 };
@@ -964,18 +964,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
 
 // ------------------------------------------------------------------------------------------
 // TN kernel v3: 256(n) x 256(k) output tile, 16 waves (4 x 4, each 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 as in v2), ONE
-// workgroup per CU.  rocprofv3 SQ counters of v2 in the step (profiles/r02_pmc_sq_*.txt): 51 % of the wave-cycles parked
-// on s_waitcnt / barriers, matrix pipe busy 29 % -- the 128x128 tiles pull 2.8 GB through L2 per launch (~20 TB/s) with
-// at most 64 KB in flight per CU, i.e. the loop waits for operand delivery.  A 256x256 tile halves the operand bytes per
-// FLOP and gives every DMA twice as many matrix-cycles to land; the LDS images, the DMA map, the swizzle and the
-// transposed fragment reads are v2's (a stage = four [64][128] images: P0 P1 Q0 Q1, 64 KB; two stages).
+// workgroup per CU, FOUR-stage LDS ring of 32-row stages.  rocprofv3 SQ counters of v2 in the step
+// (profiles/r02_pmc_sq_v1.txt): 51 % of the wave-cycles parked on s_waitcnt / barriers, matrix pipe busy 29 % -- the
+// 128x128 tiles pull 2.8 GB through L2 per launch with at most 64 KB in flight per CU, i.e. the loop waits for operand
+// delivery.  A 256x256 tile halves the operand bytes per FLOP.  One workgroup per CU has no second workgroup to cover
+// its stalls, so (first version: two 64-row stages, 823-974 TF/s on cache-warm operands but 440 TF/s in the step, where
+// the stashed activations come from HBM) the ring keeps three stages = 96 KB in flight behind the stage being
+// multiplied: a DMA has three stages of matrix work to land.  The LDS images, the DMA map, the swizzle and the transposed
+// fragment reads are v2's (a stage = four [32][128] images: P0 P1 Q0 Q1).
 // Needs Nn, Kk multiples of 256 (every ViT-B/32 / ViT-L/14 block weight is); other shapes stay on v2.
-// A launch with a single M split owns every output element exactly once, so it adds with a plain read-modify-write
-// (6 TB/s class) instead of memory-side float atomics (1.3 TB/s chip-wide, MI355X_MICROARCH.md "Global float atomics").
 // ------------------------------------------------------------------------------------------
-constexpr int T3_IMG_BYTES = TN_BM * 256;                // 16 KiB: 64 rows x 128 columns
-constexpr int T3_STAGE_BYTES = 4 * T3_IMG_BYTES;         // 64 KiB
-constexpr int T3_LDS_BYTES = 2 * T3_STAGE_BYTES;         // 128 KiB
+constexpr int T3_ROWS = 32;                              // contraction rows per stage
+constexpr int T3_IMG_BYTES = T3_ROWS * 256;              // 8 KiB: 32 rows x 128 columns
+constexpr int T3_STAGE_BYTES = 4 * T3_IMG_BYTES;         // 32 KiB: P0 P1 Q0 Q1
+constexpr int T3_STAGES = 4;                             // ring: three stages in flight behind the one being multiplied
+constexpr int T3_LDS_BYTES = T3_STAGES * T3_STAGE_BYTES; // 128 KiB
 
 __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1024,25 +1027,26 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
     const int ms = mt0 * TN_BM;
     const int rows = min(grp.M, mt1 * TN_BM) - ms;
 
-    // DMA: wave w fills image w>>2 (P0 P1 Q0 Q1), instructions (w&3)*4 .. +3 of its 16 (4 rows x 256 B each)
+    // DMA: wave w fills image w>>2 (P0 P1 Q0 Q1) of a stage, instructions (w&3)*2, +1 of its 8 (4 rows x 256 B each):
+    // every wave issues exactly TWO DMA instructions per stage (the unit of the vmcnt bookkeeping below)
     const int img = wave >> 2;
     const bool isP = img < 2;
     const long ld = isP ? p.ldp : p.ldq;
     const bf16_t* src = isP ? p.P : p.Q;
     const int col0 = (isP ? n0 : k0) + 128 * (img & 1);
     const u32x4 rsrc = make_rsrc_words(src + (long)ms * ld, (uint32_t)((long)rows * ld * 2));
-    uint32_t vo[4];
+    uint32_t vo[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = ((wave & 3) * 4 + j) * 4 + s_r;
+    for (int j = 0; j < 2; ++j) {
+        const int row = ((wave & 3) * 2 + j) * 4 + s_r;
         vo[j] = (uint32_t)(row * ld * 2 + (col0 + s_chunk * 8) * 2);
     }
-    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + img * T3_IMG_BYTES + (wave & 3) * 4096;
-    auto stage = [&](int st, int mt) {
-        const uint32_t d = lds0 + st * T3_STAGE_BYTES;
-        const uint32_t mb = (uint32_t)((long)mt * TN_BM * ld * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16_bounds(rsrc, d + j * 1024, vo[j] + mb);
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + img * T3_IMG_BYTES + (wave & 3) * 2048;
+    auto stage = [&](int slot, int st) {
+        const uint32_t d = lds0 + slot * T3_STAGE_BYTES;
+        const uint32_t mb = (uint32_t)((long)st * T3_ROWS * ld * 2);
+        dma16_bounds(rsrc, d, vo[0] + mb);
+        dma16_bounds(rsrc, d + 1024, vo[1] + mb);
     };
 
     f32x16 acc[2][2];
@@ -1051,16 +1055,25 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
         acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
     }
 
-    const int nmt = mt1 - mt0;
+    // ring of T3_STAGES stages, prefetch distance 3: a DMA has three stages of matrix work (~3 x 1024 cycles per SIMD)
+    // to land, and 96 KB are in flight per CU.  Iteration i: wait until this wave's part of stage i has landed (its two
+    // later stages may still be in flight: vmcnt(4)), barrier (= every wave's part has landed AND every wave has finished
+    // reading stage i-1), refill the slot of stage i-1 with stage i+3, multiply stage i.
+    const int nst = (rows + T3_ROWS - 1) / T3_ROWS;
+    const int D = grp.depth;                               // stages issued ahead of the one being multiplied (1..3)
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int mt = 0; mt < nmt; ++mt) {
-        const int cur = mt & 1;
-        if (mt + 1 < nmt) stage(cur ^ 1, mt + 1);
-        const char* st = smem + cur * T3_STAGE_BYTES;
+    if (nst > 1 && D > 1) stage(1, 1);
+    if (nst > 2 && D > 2) stage(2, 2);
+    for (int i = 0; i < nst; ++i) {
+        const int later = min(nst - 1 - i, D - 1);         // stages i+1 .. issued and not yet needed
+        if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + D < nst) stage((i + D) & 3, i + D);
+        const char* st = smem + (i & 3) * T3_STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
             bf16x8 pf[2], qf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1073,13 +1086,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
                 for (int kt = 0; kt < 2; ++kt)
                     acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[nt], qf[kt], acc[nt][kt], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage landed (this wave's DMA)
-        __syncthreads();
     }
 
     const int ek = k0 + wk * 64 + (lane & 31);
     const int en = n0 + wn * 64 + 4 * (lane >> 5);
-    constexpr bool sole = false;             // see gemm_tn2_kernel: read-modify-write measured slower than atomics
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -1088,9 +1098,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
-                float* o = p.out + (long)n * p.ldo + k;
-                if (sole) *o += acc[nt][kt][r];
-                else atomicAdd(o, acc[nt][kt][r]);
+                atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
             }
         }
 }
@@ -1325,8 +1333,8 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
                                   const long* ldo, int splits, void* stream) {
     CE_CHECK_ARG(count >= 1 && count <= CE_TN_MAX_GROUP && M > 0, "ce_gemm_tn_grouped: 1..%d problems, M > 0", CE_TN_MAX_GROUP);
     static std::once_flag attr_set;
-    static int variant = 2;   // CE_GEMM_TN: 1 = register-staged v1 kernel (one launch per problem), 2 = 128x128 v2 (default),
-                              // 3 = 256x256 v3 where the shapes allow (faster on cache-warm operands, slower in the step)
+    static int variant = 3;   // CE_GEMM_TN: 1 = register-staged v1 kernel (one launch per problem), 2 = 128x128 v2,
+                              // 3 (default) = 256x256 ring kernel v3 where the shapes allow, v2 elsewhere
     std::call_once(attr_set, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TN_LDS_BYTES);
@@ -1406,13 +1414,15 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         else if (force_splits > 0) sp = force_splits;
         else {
             double best = cost(1);
-            for (int c = 2; c <= 16 && c <= m_tiles; ++c)
-                if (cost(c) < best) { best = cost(c); sp = c; }
+            for (int c = 2; c <= 16 && c <= m_tiles && (long)tiles3 * c <= 256; ++c)     // split only within one resident round:
+                if (cost(c) < best) { best = cost(c); sp = c; }                         // every split tile costs atomic bandwidth
         }
         if (sp > m_tiles) sp = m_tiles;
         if (sp < 1) sp = 1;
         g.m_per_split = ce_div_up(m_tiles, sp) * TN_BM;
         g.splits = ce_div_up(M, g.m_per_split);
+        static int depth = getenv("CE_TN3_DEPTH") ? atoi(getenv("CE_TN3_DEPTH")) : 3;
+        g.depth = depth < 1 ? 1 : (depth > 3 ? 3 : depth);
         CeProfScope prof(CE_PROF_GEMM_TN, flops, bytes, s);
         hipLaunchKernelGGL(gemm_tn3_kernel, dim3((unsigned)(tiles3 * g.splits)), dim3(1024), T3_LDS_BYTES, s, g);
         CE_LAUNCH_CHECK();
