@@ -43,6 +43,43 @@ class _BBoxPoolFn(torch.autograd.Function):
         return dgrid, None
 
 
+class _RegionNCEFn(torch.autograd.Function):
+    """(loss_per_bbox, loss_per_arg) of model_clip.py:456-488 over every image group (``ce_region_nce_fwd/bwd``)."""
+
+    @staticmethod
+    def forward(ctx, region, desc_f, lab_f, logit_scale, offsets, groups, max_rows, use_label, role_text):
+        region, desc_f = region.contiguous().float(), desc_f.contiguous().float()
+        lab_f = lab_f.contiguous().float() if lab_f is not None else None
+        ls = logit_scale.detach().reshape(1)
+        out = torch.zeros(2, dtype=torch.float32, device=region.device)
+        check(lib().ce_region_nce_fwd(ptr(region), ptr(desc_f), ptr(lab_f), ptr(offsets), c_int(groups), c_int(max_rows),
+                                      c_int(region.shape[1]), ptr(ls), c_int(1 if use_label else 0),
+                                      c_int(1 if role_text else 0), ptr(out[0:1]), ptr(out[1:2]), stream()),
+              "ce_region_nce_fwd")
+        ctx.saved = (region, desc_f, lab_f, ls, offsets)
+        ctx.cfg = (groups, max_rows, use_label, role_text)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_bbox, g_arg):
+        region, desc_f, lab_f, ls, offsets = ctx.saved
+        groups, max_rows, use_label, role_text = ctx.cfg
+        dev = region.device
+        g = torch.zeros(2, dtype=torch.float32, device=dev)
+        if g_bbox is not None:
+            g[0] = g_bbox
+        if g_arg is not None:
+            g[1] = g_arg
+        dr, dd = torch.zeros_like(region), torch.zeros_like(desc_f)
+        dl = torch.zeros_like(lab_f) if lab_f is not None else None
+        dls = torch.zeros(1, dtype=torch.float32, device=dev)
+        check(lib().ce_region_nce_bwd(ptr(region), ptr(desc_f), ptr(lab_f), ptr(offsets), c_int(groups), c_int(max_rows),
+                                      c_int(region.shape[1]), ptr(ls), c_int(1 if use_label else 0),
+                                      c_int(1 if role_text else 0), ptr(g[0:1]), ptr(g[1:2]), ptr(dr), ptr(dd), ptr(dl),
+                                      ptr(dls), stream()), "ce_region_nce_bwd")
+        return dr, dd, dl, dls.reshape(()), None, None, None, None, None
+
+
 def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg: str):
     dev = grid_features.device
     pn = model.visual.patch_num
@@ -79,20 +116,11 @@ def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, tr
     region = _BBoxPoolFn.apply(grid_features, boxes)                                  # [nbox, E]
     desc_f = model.encode_text(torch.stack(descs).to(dev))                            # one tower pass for all roles
     lab_f = model.encode_text(torch.stack(labs).to(dev)) if use_label else None
-    loss_per_bbox, loss_per_arg = zero, zero
-    for start, n in groups:
-        r = region[start:start + n]
-        d = desc_f[start:start + n]
-        y = torch.arange(n, device=dev)
-        lpb, lpa = logits_from_features(r, d, model.logit_scale, True)               # s r d^T , s d r^T
-        loss_per_bbox = loss_per_bbox + model.loss_func(lpb, y)
-        loss_per_arg = loss_per_arg + model.loss_func(lpa, y)
-        if use_label:
-            l = lab_f[start:start + n]
-            lpb2, lpa2 = logits_from_features(r, l, model.logit_scale, True)
-            loss_per_bbox = loss_per_bbox + model.loss_func(lpb2, y)
-            loss_per_arg = loss_per_arg + model.loss_func(lpa2, y)
-            if use_role_text:
-                lpr, _ = logits_from_features(d, l, model.logit_scale, True, want="image")   # s d l^T
-                loss_per_arg = loss_per_arg + model.loss_func(lpr, y)
-    return loss_per_bbox, loss_per_arg
+    offsets = torch.tensor([g[0] for g in groups] + [groups[-1][0] + groups[-1][1]], dtype=torch.int32, device=dev)
+    max_rows = max(n for _, n in groups)
+    if max_rows > 16:
+        raise RuntimeError(f"{max_rows} boxes in one image: the region InfoNCE kernel takes at most 16")
+    # all images' n x n InfoNCE terms, both directions and the label / role-text variants, in one launch (and one for
+    # the backward): launch count independent of the batch size (the reference loops over images, :456-488)
+    return _RegionNCEFn.apply(region, desc_f, lab_f, model.logit_scale, offsets, len(groups), max_rows, use_label,
+                              use_role_text)

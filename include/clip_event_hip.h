@@ -286,6 +286,20 @@ int ce_bbox_pool_fwd(const float* grid, long sb, long s0, long s1, const int* bo
                      void* stream);
 int ce_bbox_pool_bwd(const float* dout, const int* boxes, float* dgrid, int g, int nbox, int E, void* stream);
 
+/* Region / argument InfoNCE of the train_arg branch (model_clip.py:456-488) for every image of the batch in one
+ * launch.  region / desc / label: f32 [R,E] rows grouped per image, image g owning rows offsets[g] .. offsets[g+1]-1 (at
+ * most 16; max_rows = the largest group, checked on the host); label may be NULL when use_label = 0.  Adds
+ *   loss_bbox += sum_g CE(s r^ d^T) [+ CE(s r^ l^T)],  loss_arg += sum_g CE(s d^ r^T) [+ CE(s l^ r^T)] [+ CE(s d^ l^T)]
+ * (x^ = x/|x|, s = exp(*logit_scale), targets arange(n), mean over the n rows; the l terms with use_label, the last with
+ * role_text).  The backward takes the upstream scalars g_bbox / g_arg (device) and writes dregion / ddesc / dlabel (the
+ * caller zero-fills them) and adds the logit_scale gradient. */
+int ce_region_nce_fwd(const float* region, const float* desc, const float* label, const int* offsets, int groups,
+                      int max_rows, int E, const float* logit_scale, int use_label, int role_text, float* loss_bbox,
+                      float* loss_arg, void* stream);
+int ce_region_nce_bwd(const float* region, const float* desc, const float* label, const int* offsets, int groups,
+                      int max_rows, int E, const float* logit_scale, int use_label, int role_text, const float* g_bbox,
+                      const float* g_arg, float* dregion, float* ddesc, float* dlabel, float* dlogit_scale, void* stream);
+
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);
 int ce_probe_tr16(const void* image, int n_elems, const int* byte_off, void* out, void* stream);
