@@ -6,13 +6,14 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 import sys
 from typing import Dict, Optional
 
 import torch
 
 from . import distributed as D
-from .functional import logits_from_features
+from .functional import fused_contrastive_losses, fused_head_ok, logits_from_features
 from .losses import CriterionAlignment, CriterionContrastive
 
 
@@ -30,14 +31,24 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
     are per-image sums over the local batch, no exchange."""
     model = _unwrap(model)
     extra = {}
-    if D.active() and global_batch:
+    # fused head (no logits matrix in HBM): the 'ce' criterion over the batch, SURVEY 8(a) a6.  CE_FUSED_HEAD=0 keeps the
+    # logits + criterion path (the one the reference API exposes; same values).
+    fused = (os.environ.get("CE_FUSED_HEAD", "1") != "0" and getattr(criterion, "kind", None) == "ce"
+             and model.constrastive_overbatch and fused_head_ok(model.embed_dim))
+    dist_global = D.active() and global_batch
+    if dist_global or fused:
         if train_arg is None:
             fi, ft = model.encode_both(image, text)
         else:
             fi, ft, loss_bbox, loss_arg = model.encode_with_regions(image, text, train_arg, bboxs, bbox_desc_vec,
                                                                     bbox_label_vec)
             extra = {"loss_bbox": loss_bbox, "loss_arg": loss_arg}
-        fi_all, ft_all = D.gather_feature_pair(fi, ft)
+        fi_all, ft_all = D.gather_feature_pair(fi, ft) if dist_global else (fi, ft)
+        if fused:
+            loss_dict = fused_contrastive_losses(fi, ft, fi_all, ft_all, model.logit_scale, labels_per_image,
+                                                 labels_per_text, index_pos)
+            loss_dict.update(extra)
+            return loss_dict
         overbatch = model.constrastive_overbatch
         lpi, _ = logits_from_features(fi, ft_all if overbatch else ft, model.logit_scale, overbatch, want="image")
         _, lpt = logits_from_features(fi_all, ft, model.logit_scale, True, want="text")

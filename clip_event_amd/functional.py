@@ -404,3 +404,61 @@ def logits_from_features(image_features, text_features, logit_scale, overbatch: 
     """``want`` in {"both", "image", "text"}: skip the logits matrix that is not needed (global-batch
     path: each rank needs only its own row blocks)."""
     return LogitsFn.apply(image_features, text_features, logit_scale, bool(overbatch), want)
+
+
+class InfoNCEFn(torch.autograd.Function):
+    """mean_r CE(s q^_r . k^_c, label_r) over the query rows ``sel`` (index_pos) of ``q`` against all rows of ``k`` --
+    model_clip.py:496-521 + :633-662 for one direction -- without the [nq, nk] logits matrix (``ce_infonce_fwd/bwd``:
+    similarity tiles on the fp32 matrix instruction, online log-sum-exp, backward from the saved log-sum-exp)."""
+
+    @staticmethod
+    def forward(ctx, q, k, logit_scale, labels, sel):
+        cl, s = lib(), stream()
+        dev = q.device
+        q, k = _f32(q), _f32(k)
+        E = q.shape[1]
+        qn, kn = torch.empty_like(q), torch.empty_like(k)
+        inv_q, inv_k = _empty((q.shape[0],), torch.float32, dev), _empty((k.shape[0],), torch.float32, dev)
+        check(cl.ce_l2norm_fwd(ptr(q), c_long(E), ptr(qn), c_long(E), ptr(inv_q), c_int(q.shape[0]), c_int(E), s), "ce_l2norm_fwd")
+        check(cl.ce_l2norm_fwd(ptr(k), c_long(E), ptr(kn), c_long(E), ptr(inv_k), c_int(k.shape[0]), c_int(E), s), "ce_l2norm_fwd")
+        labels = labels.to(device=dev, dtype=torch.int64).contiguous()
+        sel = sel.to(device=dev, dtype=torch.int64).contiguous() if sel is not None else None
+        nq = q.shape[0] if sel is None else sel.shape[0]
+        ls = logit_scale.detach().reshape(1)
+        lse = _empty((nq,), torch.float32, dev)
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        cl.ce_infonce_workspace_bytes.restype = ctypes.c_size_t
+        ws = _empty((int(cl.ce_infonce_workspace_bytes(c_int(nq))),), torch.uint8, dev)
+        check(cl.ce_infonce_fwd(ptr(qn), c_long(E), ptr(sel), c_int(nq), ptr(kn), c_long(E), c_int(k.shape[0]), c_int(E),
+                                ptr(ls), ptr(labels), ptr(lse), ptr(loss), ptr(ws), s), "ce_infonce_fwd")
+        ctx.saved = (qn, kn, inv_q, inv_k, ls, labels, sel, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        cl, s = lib(), stream()
+        qn, kn, inv_q, inv_k, ls, labels, sel, lse = ctx.saved
+        E = qn.shape[1]
+        nq = qn.shape[0] if sel is None else sel.shape[0]
+        g = g.contiguous().float().reshape(1)
+        dqn, dkn = torch.zeros_like(qn), torch.zeros_like(kn)
+        dls = torch.zeros(1, dtype=torch.float32, device=qn.device)
+        check(cl.ce_infonce_bwd(ptr(qn), c_long(E), ptr(sel), c_int(nq), ptr(kn), c_long(E), c_int(kn.shape[0]), c_int(E),
+                                ptr(ls), ptr(labels), ptr(lse), ptr(g), ptr(dqn), ptr(dkn), ptr(dls), s), "ce_infonce_bwd")
+        dq, dk = torch.empty_like(qn), torch.empty_like(kn)
+        check(cl.ce_l2norm_bwd(ptr(dqn), c_long(E), ptr(qn), c_long(E), ptr(inv_q), ptr(dq), c_long(E), c_int(qn.shape[0]),
+                               c_int(E), c_int(0), s), "ce_l2norm_bwd")
+        check(cl.ce_l2norm_bwd(ptr(dkn), c_long(E), ptr(kn), c_long(E), ptr(inv_k), ptr(dk), c_long(E), c_int(kn.shape[0]),
+                               c_int(E), c_int(0), s), "ce_l2norm_bwd")
+        return dq, dk, dls.reshape(()), None, None
+
+
+def fused_head_ok(embed_dim: int) -> bool:
+    return embed_dim % 128 == 0 and 128 <= embed_dim <= 1024
+
+
+def fused_contrastive_losses(fi, ft, fi_all, ft_all, logit_scale, labels_per_image, labels_per_text, index_pos):
+    """``CriterionContrastive('ce')`` over the batch on raw features: loss_i = CE(s I^ T_all^T, labels_per_image),
+    loss_t = CE over the ``index_pos`` rows of s T^ I_all^T (model_clip.py:633-662), the logits never materialised."""
+    return {"loss_i": InfoNCEFn.apply(fi, ft_all, logit_scale, labels_per_image, None),
+            "loss_t": InfoNCEFn.apply(ft, fi_all, logit_scale, labels_per_text, index_pos)}

@@ -286,6 +286,23 @@ int ce_bbox_pool_fwd(const float* grid, long sb, long s0, long s1, const int* bo
                      void* stream);
 int ce_bbox_pool_bwd(const float* dout, const int* boxes, float* dgrid, int g, int nbox, int E, void* stream);
 
+/* Fused contrastive head for the 'ce' criterion over the batch (model_clip.py:496-521 logits + :633-662 cross entropy)
+ * that never forms the [nq, nk] logits matrix (336 MB at N = 4096, K = 5): q [.,E], k [nk,E] are L2-NORMALISED fp32
+ * features (ce_l2norm_fwd), query r = row sel[r] of q (sel nullable: row r), its target column labels[sel[r]].
+ *   fwd: lse[r] = log sum_c exp(s <q_r, k_c>), *loss += mean_r (lse[r] - s <q_r, k_label>), s = exp(*logit_scale);
+ *        workspace = ce_infonce_workspace_bytes(nq) bytes of scratch.
+ *   bwd: for the upstream scalar *grad: dq[sel[r],:] += s sum_c G[r,c] k_c, dk[c,:] += s sum_r G[r,c] q_r,
+ *        *dlogit_scale += sum G[r,c] s <q_r,k_c>, G = grad/nq (softmax_r - onehot); dq / dk are gradients w.r.t. the
+ *        normalised features (feed ce_l2norm_bwd) and must be zero-filled (or hold earlier contributions).
+ * fp32 on v_mfma_f32_32x32x2_f32; E a multiple of 128, 128..1024. */
+#define CE_INFONCE_MAX_SPLITS 64
+size_t ce_infonce_workspace_bytes(int nq);
+int ce_infonce_fwd(const float* q, long ldq, const int64_t* sel, int nq, const float* k, long ldk, int nk, int E,
+                   const float* logit_scale, const int64_t* labels, float* lse, float* loss, void* workspace, void* stream);
+int ce_infonce_bwd(const float* q, long ldq, const int64_t* sel, int nq, const float* k, long ldk, int nk, int E,
+                   const float* logit_scale, const int64_t* labels, const float* lse, const float* grad, float* dq, float* dk,
+                   float* dlogit_scale, void* stream);
+
 /* Region / argument InfoNCE of the train_arg branch (model_clip.py:456-488) for every image of the batch in one
  * launch.  region / desc / label: f32 [R,E] rows grouped per image, image g owning rows offsets[g] .. offsets[g+1]-1 (at
  * most 16; max_rows = the largest group, checked on the host); label may be NULL when use_label = 0.  Adds

@@ -149,3 +149,37 @@ def test_fixed_batch_is_fitted():
     assert all(l == l for l in losses)
     print("loss", [round(l, 3) for l in losses[::5]], "->", losses[-1])
     assert losses[-1] < 0.05 * losses[0]
+
+
+def test_fused_head_equals_logits_plus_criterion_path():
+    """ViT-B/32, B = 8, K = 3 hard negatives: the fused head (no logits matrix, engine default) and the reference-shaped
+    path (model.forward logits + CriterionContrastive) give the same losses (1e-5) and the same parameter gradients to
+    bf16 rounding (relative 5e-3, measured 2.1e-3: the two fp32 heads agree to 1e-7, but the towers' backward rounds
+    the feature gradient to bf16 first, so 1-ulp differences flip roundings -- the level of the packed-vs-dense test)."""
+    import os
+    from clip_event_amd import synthetic as S, distributed as D
+    from clip_event_amd.engine import contrastive_step_losses
+    from clip_event_amd.losses import CriterionContrastive
+    m = S.synthetic_model("vit_b32", seed=3).to(DEV)
+    B, K = 8, 3
+    img = S.synthetic_images(B, 224, seed=5).to(DEV)
+    txt = S.synthetic_tokens(B * K, 77, 49408, seed=6).to(DEV)
+    yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=DEV, rank_=0)
+    crit = CriterionContrastive("ce")
+    out = {}
+    for fused in ("1", "0"):
+        os.environ["CE_FUSED_HEAD"] = fused
+        try:
+            m.zero_grad()
+            ld = contrastive_step_losses(m, crit, img, txt, yi, yt, ip)
+            sum(ld.values()).backward()
+            torch.cuda.synchronize()
+            out[fused] = ({k: float(v) for k, v in ld.items()}, m._flat_grad.clone())
+        finally:
+            os.environ.pop("CE_FUSED_HEAD", None)
+    print("fused", out["1"][0], "unfused", out["0"][0])
+    for k in ("loss_i", "loss_t"):
+        assert abs(out["1"][0][k] - out["0"][0][k]) < 1e-5 * max(1.0, abs(out["0"][0][k]))
+    rel = float((out["1"][1] - out["0"][1]).norm() / out["0"][1].norm())
+    print("flat gradient rel-l2 fused vs unfused:", rel)
+    assert rel < 5e-3

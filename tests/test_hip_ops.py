@@ -389,3 +389,38 @@ def test_gemm_nt_fp8_epilogues():
     want = acc * (s * (1 + 1.702 * x * (1 - s)))
     assert _report("fp8 gelugrad", o, want)[1] < 3e-3
     assert _report("fp8 gelugrad colsum", colsum.cpu(), want.sum(0))[1] < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused contrastive head (no logits matrix)
+
+@pytest.mark.parametrize("nq,nk,E,use_sel", [(70, 333, 128, True), (256, 256, 512, False), (33, 1000, 512, True),
+                                             (512, 2560, 512, False), (40, 96, 768, True), (5, 7, 128, False)])
+def test_fused_infonce_against_pytorch(nq, nk, E, use_sel):
+    """ce_infonce_fwd/bwd against fp32 PyTorch autograd of  mean CE(s q^ k^T, labels)  on the selected query rows:
+    loss and log-sum-exp 1e-5, gradients w.r.t. the RAW features and logit_scale 2e-5 relative (fp32 MFMA = exact
+    fp32 FMA chains: summation order only).  Ragged sizes, query gather, labels anywhere in the key range."""
+    from clip_event_amd.functional import InfoNCEFn
+    rng = np.random.default_rng(nq * 31 + nk + E)
+    rows_q = nq + 9 if use_sel else nq
+    q = _randn(rng, rows_q, E).requires_grad_(True)
+    k = _randn(rng, nk, E).requires_grad_(True)
+    ls = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+    sel = torch.from_numpy(rng.permutation(rows_q)[:nq].astype(np.int64)) if use_sel else None
+    labels = torch.from_numpy(rng.integers(0, nk, size=rows_q).astype(np.int64))
+    qs = q if sel is None else q.index_select(0, sel)
+    ys = labels if sel is None else labels.index_select(0, sel)
+    logits = ls.exp() * torch.nn.functional.normalize(qs, dim=-1) @ torch.nn.functional.normalize(k, dim=-1).t()
+    ref = torch.nn.functional.cross_entropy(logits, ys)
+    (ref * 1.3).backward()
+    qd = q.detach().to(DEV).requires_grad_(True)
+    kd = k.detach().to(DEV).requires_grad_(True)
+    lsd = ls.detach().to(DEV).requires_grad_(True)
+    loss = InfoNCEFn.apply(qd, kd, lsd, labels.to(DEV), None if sel is None else sel.to(DEV))
+    (loss * 1.3).backward()
+    torch.cuda.synchronize()
+    print(f"[infonce {nq}x{nk}x{E}] loss {float(loss):.6f} (ref {float(ref):.6f})")
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert _report("infonce dq", qd.grad.cpu(), q.grad)[1] < 2e-5
+    assert _report("infonce dk", kd.grad.cpu(), k.grad)[1] < 2e-5
+    assert abs(float(lsd.grad) - float(ls.grad)) < 2e-5 * max(1.0, abs(float(ls.grad)))
