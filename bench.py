@@ -322,8 +322,10 @@ def main():
             "value": round(pairs_per_s, 2), "unit": "pairs/s (whole job)", "per_gpu": round(pairs_per_s / W, 2),
             "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=%d, InfoNCE only, full train step "
-                                   "(fwd+bwd+clip_grad_norm+Adam), random-init weights" % (B, K),
+            "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=%d, %s, full train step "
+                                   "(fwd+bwd+clip_grad_norm+Adam), random-init weights"
+                                   % (B, K, "InfoNCE only" if not extra else "InfoNCE" + (" + OT alignment" if args.alignment else "")
+                                      + (" + region branch (%s)" % args.train_arg if args.train_arg else "")),
                        "global_batch": B * W, "parallelism": "dp%d" % W, "loss": round(loss, 4),
                        "captions": "SOT + U[8,75] random ids + EOT, zero-padded to 77 (SURVEY 8(d) c2)",
                        "text_rows": ("all 77 positions" if args.dense_text else
