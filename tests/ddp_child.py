@@ -33,6 +33,46 @@ class _GradOnly:
         pass
 
 
+def wrapper_case(rank, W, dev, sd, cfg, B, img_all, txt_all, crit):
+    """The reference's loop verbatim (engine.py:48-53, :87-90) on ``distributed.DistributedDataParallel(model)``:
+    forward through the wrapper, LOCAL-batch criterion, ``backward()`` -- the gradients must be the rank mean when it
+    returns (no explicit finish), i.e. equal the single-process gradient of the mean of the per-shard losses."""
+    from clip_event_amd import distributed as D
+    from clip_event_amd.model import build_model
+    m = build_model({k: v.clone() for k, v in sd.items()}).to(dev)
+    model = D.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+    y = torch.arange(B, device=dev)
+    img, txt = img_all[rank * B:(rank + 1) * B].to(dev), txt_all[rank * B:(rank + 1) * B].to(dev)
+    for _ in range(2):
+        m.zero_grad()
+        li, lt = model(img, txt)
+        ld = crit(li, lt, y, y, index_pos=y, constrastive_overbatch=model.module.constrastive_overbatch)
+        sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    g = m._flat_grad.detach().clone()
+    ok = True
+    if rank == 0:
+        with D.local_only():
+            m1 = build_model({k: v.clone() for k, v in sd.items()}).to(dev)
+            m1.zero_grad()
+            total = 0
+            for r in range(W):
+                li, lt = m1(img_all[r * B:(r + 1) * B].to(dev), txt_all[r * B:(r + 1) * B].to(dev))
+                ld1 = crit(li, lt, y, y, index_pos=y)
+                total = total + sum(ld1.values()) / W
+            total.backward()
+            torch.cuda.synchronize()
+        rel = float((g - m1._flat_grad).norm() / m1._flat_grad.norm())
+        print(f"[wrapper] gradient after backward() vs mean of per-shard gradients: rel-L2 {rel:.2e}", flush=True)
+        ok = rel < 2e-3
+        print(f"[wrapper] {'OK' if ok else 'FAILED'}", flush=True)
+    flag = torch.tensor([1 if ok else 0])
+    dist.broadcast(flag, src=0)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag) == 1 else 1)
+
+
 def main():
     rank, W = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     case = os.environ.get("CASE", "k1")
@@ -70,6 +110,9 @@ def main():
             kw.update(train_arg=region, bboxs=boxes[lo:hi], bbox_desc_vec=desc[lo:hi], bbox_label_vec=lab[lo:hi])
         yi, yt, ip = D.global_labels(hi - lo, 1, K - 1, True, device=dev, rank_=r)
         return (img_all[lo:hi].to(dev), txt_all[lo * K:hi * K].to(dev), yi, yt, ip), kw
+
+    if case == "wrapper":
+        return wrapper_case(rank, W, dev, sd, cfg, B, img_all, txt_all, crit)
 
     # ---- the W-rank step: real GradSync, every collective of the path ----
     m = build_model({k: v.clone() for k, v in sd.items()}).to(dev)

@@ -2,7 +2,8 @@
 processes (gloo, both on cuda:0) against the single-process run on the concatenated batch (SURVEY.md 8(e), H3;
 reference contract: DistributedDataParallel, train.py:222-225; gather pattern utils.py:192-206).  Cases: K = 1,
 K = 5 hard negatives, alignment (two passes per tower), the region branch (three text passes), and config 4's
-combination."""
+combination; and the reference's own loop on ``distributed.DistributedDataParallel(model)`` (local-batch loss, gradients
+averaged by the time ``backward()`` returns)."""
 import os
 import socket
 import subprocess
@@ -44,7 +45,7 @@ def run_ranks(script, case, W=2, timeout=420, extra_env=None):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("case", ["k1", "k5", "align", "region", "all"])
+@pytest.mark.parametrize("case", ["k1", "k5", "align", "region", "all", "wrapper"])
 def test_two_rank_step_equals_concatenated_batch(case):
     rcs, outs = run_ranks("ddp_child.py", case)
     print(outs[0][-3000:])
