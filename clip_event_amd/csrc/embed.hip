@@ -25,6 +25,17 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict_
         const long row = idx / (Kp / 8);
         const int gx = (int)(row % grid), gy = (int)((row / grid) % grid), b = (int)(row / ((long)grid * grid));
         float v[8];
+        if (ps % 8 == 0 && R % 4 == 0) {
+            // patch sizes 16 / 32: the 8 columns are 8 consecutive pixels of one image row -> two 16-byte loads
+            const int col = cg * 8;
+            const int c = col / (ps * ps), py = (col / ps) % ps, px = col % ps;
+            const float* src = img + (((long)b * 3 + c) * R + gy * ps + py) * R + gx * ps + px;
+            const f32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+            const f32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 4));
+            u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+            *reinterpret_cast<u32x4*>(out + row * Kp + cg * 8) = pk;
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int col = cg * 8 + e;

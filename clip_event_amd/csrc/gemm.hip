@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
 
 // ------------------------------------------------------------------------------------------
 // TN kernel v3: 256(n) x 256(k) output tile, 16 waves (4 x 4, each 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 as in v2), ONE
-// workgroup per CU, FOUR-stage LDS ring of 32-row stages.  rocprofv3 SQ counters of v2 in the step
+// workgroup per CU, LDS ring of 48-row stages x 3 slots (or 32-row stages x 4 slots).  rocprofv3 SQ counters of v2 in the step
 // (profiles/r02_pmc_sq_v1.txt): 51 % of the wave-cycles parked on s_waitcnt / barriers, matrix pipe busy 29 % -- the
 // 128x128 tiles pull 2.8 GB through L2 per launch with at most 64 KB in flight per CU, i.e. the loop waits for operand
 // delivery.  A 256x256 tile halves the operand bytes per FLOP.  One workgroup per CU has no second workgroup to cover
@@ -974,13 +974,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(TNGroup grp) {
 // fragment reads are v2's (a stage = four [32][128] images: P0 P1 Q0 Q1).
 // Needs Nn, Kk multiples of 256 (every ViT-B/32 / ViT-L/14 block weight is); other shapes stay on v2.
 // ------------------------------------------------------------------------------------------
-constexpr int T3_ROWS = 32;                              // contraction rows per stage
-constexpr int T3_IMG_BYTES = T3_ROWS * 256;              // 8 KiB: 32 rows x 128 columns
-constexpr int T3_STAGE_BYTES = 4 * T3_IMG_BYTES;         // 32 KiB: P0 P1 Q0 Q1
-constexpr int T3_STAGES = 4;                             // ring: three stages in flight behind the one being multiplied
-constexpr int T3_LDS_BYTES = T3_STAGES * T3_STAGE_BYTES; // 128 KiB
-
+// ROWS contraction rows per stage (32: four-stage ring, 128 KiB; 48: three-stage ring, 144 KiB: fewer barriers per FLOP,
+// one stage less in flight), STAGES ring slots.  A stage = four [ROWS][128] images P0 P1 Q0 Q1.
+template <int T3_ROWS, int T3_STAGES>
 __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
+    constexpr int T3_IMG_BYTES = T3_ROWS * 256;
+    constexpr int T3_STAGE_BYTES = 4 * T3_IMG_BYTES;
+    constexpr int KSTEPS = T3_ROWS / 16;                  // 16-row MFMA k-steps per stage
+    constexpr int DPW = T3_ROWS / 16;                     // DMA instructions per wave and stage (ROWS*4 images / 4 rows / 16 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1027,26 +1028,26 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
     const int ms = mt0 * TN_BM;
     const int rows = min(grp.M, mt1 * TN_BM) - ms;
 
-    // DMA: wave w fills image w>>2 (P0 P1 Q0 Q1) of a stage, instructions (w&3)*2, +1 of its 8 (4 rows x 256 B each):
-    // every wave issues exactly TWO DMA instructions per stage (the unit of the vmcnt bookkeeping below)
+    // DMA: wave w fills image w>>2 (P0 P1 Q0 Q1) of a stage, instructions (w&3)*DPW .. of its 4*DPW (4 rows x 256 B each):
+    // every wave issues exactly DPW DMA instructions per stage (the unit of the vmcnt bookkeeping below)
     const int img = wave >> 2;
     const bool isP = img < 2;
     const long ld = isP ? p.ldp : p.ldq;
     const bf16_t* src = isP ? p.P : p.Q;
     const int col0 = (isP ? n0 : k0) + 128 * (img & 1);
     const u32x4 rsrc = make_rsrc_words(src + (long)ms * ld, (uint32_t)((long)rows * ld * 2));
-    uint32_t vo[2];
+    uint32_t vo[DPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = ((wave & 3) * 2 + j) * 4 + s_r;
+    for (int j = 0; j < DPW; ++j) {
+        const int row = ((wave & 3) * DPW + j) * 4 + s_r;
         vo[j] = (uint32_t)(row * ld * 2 + (col0 + s_chunk * 8) * 2);
     }
-    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + img * T3_IMG_BYTES + (wave & 3) * 2048;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + img * T3_IMG_BYTES + (wave & 3) * DPW * 1024;
     auto stage = [&](int slot, int st) {
         const uint32_t d = lds0 + slot * T3_STAGE_BYTES;
         const uint32_t mb = (uint32_t)((long)st * T3_ROWS * ld * 2);
-        dma16_bounds(rsrc, d, vo[0] + mb);
-        dma16_bounds(rsrc, d + 1024, vo[1] + mb);
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) dma16_bounds(rsrc, d + j * 1024, vo[j] + mb);
     };
 
     f32x16 acc[2][2];
@@ -1060,20 +1061,26 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
     // later stages may still be in flight: vmcnt(4)), barrier (= every wave's part has landed AND every wave has finished
     // reading stage i-1), refill the slot of stage i-1 with stage i+3, multiply stage i.
     const int nst = (rows + T3_ROWS - 1) / T3_ROWS;
-    const int D = grp.depth;                               // stages issued ahead of the one being multiplied (1..3)
+    const int D = min(grp.depth, T3_STAGES - 1);           // stages issued ahead of the one being multiplied
     stage(0, 0);
     if (nst > 1 && D > 1) stage(1, 1);
     if (nst > 2 && D > 2) stage(2, 2);
+    int slot = 0;
     for (int i = 0; i < nst; ++i) {
         const int later = min(nst - 1 - i, D - 1);         // stages i+1 .. issued and not yet needed
-        if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (i + D < nst) stage((i + D) & 3, i + D);
-        const char* st = smem + (i & 3) * T3_STAGE_BYTES;
+        if (i + D < nst) {
+            int sl = slot + D;
+            if (sl >= T3_STAGES) sl -= T3_STAGES;
+            stage(sl, i + D);
+        }
+        const char* st = smem + slot * T3_STAGE_BYTES;
+        slot = slot + 1 == T3_STAGES ? 0 : slot + 1;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KSTEPS; ++s) {
             bf16x8 pf[2], qf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1340,8 +1347,10 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
                             TN_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             T2_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            T3_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * 32 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_kernel<48, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            3 * 48 * 1024);
         const char* e = getenv("CE_GEMM_TN");
         if (e) variant = atoi(e);
     });
@@ -1424,7 +1433,13 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         static int depth = getenv("CE_TN3_DEPTH") ? atoi(getenv("CE_TN3_DEPTH")) : 3;
         g.depth = depth < 1 ? 1 : (depth > 3 ? 3 : depth);
         CeProfScope prof(CE_PROF_GEMM_TN, flops, bytes, s);
-        hipLaunchKernelGGL(gemm_tn3_kernel, dim3((unsigned)(tiles3 * g.splits)), dim3(1024), T3_LDS_BYTES, s, g);
+        // 48-row stages x 3 slots (default; in the step 993 TF/s) or 32-row stages x 4 slots (CE_TN3_ROWS=32: 935): one
+        // stage less in flight costs nothing (prefetch depth 2 = depth 3 above), a third fewer barriers per FLOP pays
+        static int rows48 = getenv("CE_TN3_ROWS") ? atoi(getenv("CE_TN3_ROWS")) != 32 : 1;
+        if (rows48)
+            hipLaunchKernelGGL((gemm_tn3_kernel<48, 3>), dim3((unsigned)(tiles3 * g.splits)), dim3(1024), 3 * 48 * 1024, s, g);
+        else
+            hipLaunchKernelGGL((gemm_tn3_kernel<32, 4>), dim3((unsigned)(tiles3 * g.splits)), dim3(1024), 4 * 32 * 1024, s, g);
         CE_LAUNCH_CHECK();
         return 0;
     }
