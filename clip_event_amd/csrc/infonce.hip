@@ -20,6 +20,8 @@
 //     lane movement: cdna_hip_programming.md "An accumulator tile as the next MFMA's operand"); each wave owns a quarter of
 //     E; the result leaves through an LDS transpose as whole rows (plain stores when the streamed range is not split,
 //     float atomics otherwise).
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "common.hpp"
@@ -46,20 +48,22 @@ struct HeadArgs {
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // 32x32 C/D row of reg r
 
-template <int MODE>
-__global__ __launch_bounds__(256) void infonce_kernel(HeadArgs a) {
+// NW waves per workgroup: 4 (E a multiple of 128) or 8 (E a multiple of 256: two waves per SIMD cover the global operand
+// loads that feed the MFMAs; each wave then owns an eighth of E)
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void infonce_kernel(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = a.E, pitch = E + 4;
     float* res_l = reinterpret_cast<float*>(smem);                       // [32][E+4]
-    float* part_l = res_l + HB * pitch;                                  // [4][32][33]: partial tiles / output transpose
-    float* qinfo = part_l + 4 * HB * 33;                                 // [2][32]: lse, label (as float bits) of the streamed queries (DK)
+    float* part_l = res_l + HB * pitch;                                  // [NW][32][33]: partial tiles / output transpose
+    float* qinfo = part_l + NW * HB * 33;                                 // [2][32]: lse, label (as float bits) of the streamed queries (DK)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * HB;
     const float scale = __expf(*a.logit_scale);
 
     // ---- resident block -> LDS (gathered through sel when the residents are queries) ----
-    for (int idx = tid; idx < HB * (E / 4); idx += 256) {
+    for (int idx = tid; idx < HB * (E / 4); idx += 64 * NW) {
         const int r = idx / (E / 4), c = (idx - r * (E / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r0 + r < a.nres) {
@@ -82,16 +86,16 @@ __global__ __launch_bounds__(256) void infonce_kernel(HeadArgs a) {
 
     float run_m = -INFINITY, run_l = 0.f;                 // FWD: online statistics of query j over this split
     float dls_acc = 0.f;
-    constexpr int GT = 8;                                 // gradient accumulators: up to 8 e-tiles of 32 per wave (E <= 1024)
+    constexpr int GT = 32 / NW;                           // gradient accumulators: up to 1024 / NW / 32 e-tiles of 32 per wave
     f32x16 gacc[MODE == MODE_FWD ? 1 : GT];
-    const int etiles = E / 128;                           // e-tiles of 32 columns per wave (E/4 columns per wave)
+    const int etiles = E / (32 * NW);                     // e-tiles of 32 columns per wave (E/NW columns per wave)
     if (MODE != MODE_FWD) {
 #pragma unroll
         for (int t = 0; t < GT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
     }
-    const int e_lo = wave * (E / 4);
+    const int e_lo = wave * (E / NW);
 
     const int sb0 = blockIdx.y * a.blocks_per_split;
     const int sb1 = min(sb0 + a.blocks_per_split, (a.nstr + HB - 1) / HB);
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void infonce_kernel(HeadArgs a) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* brow = res_l + j * pitch + e_lo + 4 * h;
 #pragma unroll 4
-        for (int u = 0; u < E / 32; ++u) {
+        for (int u = 0; u < E / (8 * NW); ++u) {
             f32x4 av = {0.f, 0.f, 0.f, 0.f};
             if (ivalid) av = *reinterpret_cast<const f32x4*>(arow + 8 * u);
             const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * u);
@@ -130,8 +134,10 @@ __global__ __launch_bounds__(256) void infonce_kernel(HeadArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = row_of(r, h);
-            S[r] = scale * ((part_l[(0 * HB + i) * 33 + j] + part_l[(1 * HB + i) * 33 + j]) +
-                            (part_l[(2 * HB + i) * 33 + j] + part_l[(3 * HB + i) * 33 + j]));
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += part_l[(w * HB + i) * 33 + j];
+            S[r] = scale * t;
         }
         if (MODE == MODE_FWD) {
             float mx = run_m;
@@ -241,18 +247,22 @@ __global__ __launch_bounds__(256) void infonce_merge_kernel(HeadArgs a, float* _
     }
 }
 
-size_t head_lds_bytes(int E) { return (size_t)(HB * (E + 4) + 4 * HB * 33 + 2 * HB) * 4; }
+size_t head_lds_bytes(int E, int nw) { return (size_t)(HB * (E + 4) + nw * HB * 33 + 2 * HB) * 4; }
 
 template <int MODE>
 int launch_head(HeadArgs& a, hipStream_t s) {
     static std::once_flag flag;
     std::call_once(flag, [] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)head_lds_bytes(1024));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_kernel<MODE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)head_lds_bytes(1024, 4));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_kernel<MODE, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)head_lds_bytes(768, 8));      // E = 1024 with eight partial tiles exceeds 160 KiB
     });
-    const int rb = ce_div_up(a.nres, HB), sblocks = ce_div_up(a.nstr, HB);
-    hipLaunchKernelGGL(infonce_kernel<MODE>, dim3(rb, a.splits), dim3(256), head_lds_bytes(a.E), s, a);
-    (void)sblocks;
+    const int rb = ce_div_up(a.nres, HB);
+    static const int force_nw = getenv("CE_HEAD_WAVES") ? atoi(getenv("CE_HEAD_WAVES")) : 0;
+    const bool eight = a.E % 256 == 0 && a.E <= 768 && force_nw != 4;
+    if (eight) hipLaunchKernelGGL((infonce_kernel<MODE, 8>), dim3(rb, a.splits), dim3(512), head_lds_bytes(a.E, 8), s, a);
+    else hipLaunchKernelGGL((infonce_kernel<MODE, 4>), dim3(rb, a.splits), dim3(256), head_lds_bytes(a.E, 4), s, a);
     return 0;
 }
 
