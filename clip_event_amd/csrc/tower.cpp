@@ -22,7 +22,7 @@ namespace {
 // grouped launch (ce_gemm_tn_grouped): several rounds of unsplit tiles, so each round's atomic epilogue (memory-side
 // float atomics run at 1.3 TB/s chip-wide: a 10-20 % tail of a one-round launch) overlaps the next round's contraction.  The gradient operands (bf16
 // dY buffers) of the queued blocks stay alive in a ring of WG_SETS buffer sets.
-constexpr int WG_MAX_BLOCKS = 5;            // blocks per grouped launch (x 4 problems <= CE_TN_MAX_GROUP)
+constexpr int WG_MAX_BLOCKS = 8;            // blocks per grouped launch (x 4 problems <= CE_TN_MAX_GROUP)
 constexpr int WG_SETS = WG_MAX_BLOCKS + 1;  // a block writes its own set and the next block's dxb
 
 struct Carver {
@@ -213,12 +213,38 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
     // WG_MAX_BLOCKS blocks and a block only writes sets l and l-1).
     hipStream_t ms = (hipStream_t)stream;
     const int last = d->layers - 1;
-    // blocks per grouped launch: WG_MAX_BLOCKS.  Measured in the ViT-B/32 step (128x128-tile kernel, float atomics):
-    // 1 block per launch 4.14 ms of weight-gradient time per step, 2: 3.97, 4: 4.01, 5: 3.83 -- a long unsplit multi-round
-    // launch overlaps every round's atomic epilogue with the next round's contraction and pays one ramp-up
-    int group = WG_MAX_BLOCKS;
+    // Where to cut the block sequence into grouped launches.  A launch of T unsplit 256x256 tiles takes ceil(T / 256)
+    // rounds of the 256 CUs and every round costs a full tile time, so the cuts are chosen (small dynamic programme over
+    // the blocks of this call) to minimise the total number of rounds: ViT-B/32 image tower, 108 tiles per block, 11
+    // blocks below the pruned one: 7 blocks (756 tiles, 2.95 rounds) + 4 blocks and the pruned block's in_proj (459
+    // tiles, 1.8 rounds) = 5 rounds; fixed groups of 5 took 6.  Shapes the 256x256 kernel does not take are counted in
+    // 128x128 tiles over the 512 two-per-CU slots.  CE_WGRAD_GROUP = n forces groups of n blocks.
     static const int force_group = getenv("CE_WGRAD_GROUP") ? atoi(getenv("CE_WGRAD_GROUP")) : 0;
-    if (force_group >= 1 && force_group <= WG_MAX_BLOCKS) group = force_group;
+    bool cut_after[Layout::MAX_LAYERS] = {};
+    auto plan_cuts = [&](int hi, int lo, long extra_tiles) {       // blocks hi .. lo (top-down) are about to be queued
+        const int n = hi - lo + 1;
+        if (n <= 0) return;
+        const bool big = (w % 256 == 0) && M >= 2048;
+        const long t = big ? 12L * (w / 256) * (w / 256) : 12L * ((w + 127) / 128) * ((w + 127) / 128);
+        const long slots = big ? 256 : 512;
+        long cost[Layout::MAX_LAYERS + 1];
+        int take[Layout::MAX_LAYERS + 1];
+        cost[0] = 0;
+        for (int k = 1; k <= n; ++k) {                               // k blocks, counted from the BOTTOM of the range
+            cost[k] = -1;
+            for (int g = 1; g <= WG_MAX_BLOCKS && g <= k; ++g) {     // the topmost group of those k has g blocks
+                if (force_group >= 1 && g != force_group && g != k) continue;
+                const long tiles = g * t + (k == n ? extra_tiles : 0);   // the group that starts the range inherits the queue
+                const long c = cost[k - g] + (tiles + slots - 1) / slots * 1000 + 1;   // rounds first, then fewer launches
+                if (cost[k] < 0 || c < cost[k]) { cost[k] = c; take[k] = g; }
+            }
+        }
+        int l = hi;
+        for (int k = n; k > 0; k -= take[k]) {
+            l -= take[k];
+            cut_after[l + 1] = true;                                  // flush once block l+1 has been queued
+        }
+    };
     struct Pending {
         const void* P[CE_TN_MAX_GROUP]; long ldp[CE_TN_MAX_GROUP];
         const void* Q[CE_TN_MAX_GROUP]; long ldq[CE_TN_MAX_GROUP];
@@ -288,6 +314,8 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
     } else {
         TRY(ce_cast_bf16(dx, L.dxb[top % WG_SETS], (long)M * w, stream));
     }
+    plan_cuts(top, layer_lo, pend.count > 0 ? ((w % 256 == 0 && M >= 2048) ? 3L * (w / 256) * (w / 256)
+                                                                              : 3L * ((w + 127) / 128) * ((w + 127) / 128)) : 0);
     for (int l = top; l >= layer_lo; --l) {
         const ce_block_params& p = d->blocks[l];
         BlockStash& s = L.blk[l];
@@ -315,7 +343,8 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         queue(da, 4L * w, s.h2, w, 4 * w, w, p.g_w_fc, w);
         queue(dxb_b, w, s.o, w, w, w, p.g_w_out, w);
         queue(dqkv, 3L * w, s.h1, w, 3 * w, w, p.g_w_qkv, w);
-        if (++pend.blocks >= group || pend.count + 4 > CE_TN_MAX_GROUP) TRY(flush());
+        ++pend.blocks;
+        if (cut_after[l] || pend.count + 4 > CE_TN_MAX_GROUP) TRY(flush());
         // ---- attn.in_proj : qkv = h1 Wqkv^T + bqkv ----
         TRY(linear(b8, L, dqkv, 3 * w, p.wt_qkv, p.wt8_qkv, p.st8_qkv, M, w, 3 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh1 = dqkv Wqkv

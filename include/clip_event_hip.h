@@ -75,7 +75,7 @@ int ce_gemm_tn_bias(const void* P, long ldp, const void* Q, long ldq, int M, int
 /* 1..CE_TN_MAX_GROUP weight-gradient problems sharing M in one launch (the four Linear layers of a residual block, or of
  * several consecutive blocks: with about one resident round of tiles the launch needs no M split, and an unsplit tile is
  * added by plain read-modify-write instead of float atomics) */
-#define CE_TN_MAX_GROUP 20
+#define CE_TN_MAX_GROUP 36
 int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const void* const* Q, const long* ldq, int M,
                        const int* Nn, const int* Kk, float* const* out, const long* ldo, int splits, void* stream);
 
