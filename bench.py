@@ -113,20 +113,23 @@ def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected
     + WRITE_SIZE, tools/pmc_traffic.py; PMC needs its own runs, so bench.py cannot collect it live)."""
     import glob
-    prefix = {"gemm_tn": "gemm_tn"}.get(kernel_class)        # gemm_tn3_kernel (or gemm_tn2_kernel): first = longest
     import re
 
     def version_key(path):          # r02_..._v10.json sorts after r02_..._v9.json, and r02 after r01
         nums = [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
         return (nums, os.path.getmtime(path))
 
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic*.json")),
-                   key=version_key)
-    if not prefix or not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), key=version_key)
+    if not files:
         return None, None
+    # class name -> rocprofv3 kernel row: "gemm_nt256_kernel<0,*,2> BF16" matches "gemm_nt256_kernel<0, 5, 2>";
+    # "gemm_tn" matches "gemm_tn3_kernel<48, 3>" (rows are sorted by total time: first match = the one that dominates)
+    head = kernel_class.split(" ")[0]
+    rx = "".join("\\d+" if ch == "*" else (",\\s*" if ch == "," else re.escape(ch)) for ch in head)
+    pat = re.compile("^" + rx + ("$" if "<" in head else ""))
     try:
         for row in json.load(open(files[-1])):
-            if row["kernel"].startswith(prefix):
+            if pat.match(row["kernel"]):
                 return (row["fetch_corrected_x2_MB"] + row["WRITE_SIZE_MB_per_launch"]) * 1e6, os.path.basename(files[-1])
     except Exception:
         pass
@@ -272,7 +275,7 @@ def main():
         for _ in range(n_prof):
             step()
         torch.cuda.synchronize()
-        ncls = 14
+        ncls = int(cl.ce_profile_num_classes())
         buf = (ctypes.c_double * (ncls * 4))()
         cl.ce_profile_collect(buf, ncls)
         cl.ce_profile_enable(0)

@@ -101,10 +101,12 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
 // ---- optional event profiler (runtime.cpp); a no-op unless ce_profile_enable(1) ----
 int ce_prof_begin(int cls, double flops, double bytes, hipStream_t s);
 void ce_prof_end(int idx, hipStream_t s);
+void ce_prof_retag(int idx, int cls);
 struct CeProfScope {
     int idx;
     hipStream_t s;
     CeProfScope(int cls, double flops, double bytes, hipStream_t st) : idx(ce_prof_begin(cls, flops, bytes, st)), s(st) {}
+    void retag(int cls) { ce_prof_retag(idx, cls); }      // the kernel family is known only after the tile choice
     ~CeProfScope() { ce_prof_end(idx, s); }
 };
 

@@ -1199,7 +1199,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
     });
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
-    CeProfScope prof(CE_PROF_GEMM_NT0 + EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
+    CeProfScope prof(CE_PROF_GEMM_NT0 + 5 * EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
     const int force = nt_variant();
     const bool can256 = (a.K % N2_BK == 0) && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo2 % 8 == 0 && a.ldaux % 8 == 0;
     const bool want256 = force == 256 || (force == 0 && a.M >= 1024 && a.N >= 256);
@@ -1229,6 +1229,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
         const bool half = f == 104 || (f >= 203 && f <= 205) ||
                           (f == 0 && (half_tiles <= 512 || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
+        prof.retag(CE_PROF_GEMM_NT0 + 5 * EPI + (half || f == 104 ? 1 : (use32 ? 3 : 2)));
         if (half) {
             a.tiles_n = ce_div_up(a.N, 128);
             int htm = 5;
@@ -1389,7 +1390,7 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         for (int i = 0; i < count; ++i) {
             TNArgs a = g.prob[i];
             a.splits = g.splits; a.m_per_split = g.m_per_split;
-            CeProfScope prof(CE_PROF_GEMM_TN, 2.0 * M * a.Nn * a.Kk, 0.0, s);
+            CeProfScope prof(CE_PROF_GEMM_TN2, 2.0 * M * a.Nn * a.Kk, 0.0, s);
             hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k * a.splits), dim3(256), TN_LDS_BYTES, s, a);
         }
         CE_LAUNCH_CHECK();
@@ -1449,7 +1450,7 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
     if (splits < 1) splits = 1;
     g.m_per_split = ce_div_up(m_tiles, splits) * TN_BM;
     g.splits = ce_div_up(M, g.m_per_split);
-    CeProfScope prof(CE_PROF_GEMM_TN, flops, bytes, s);
+    CeProfScope prof(CE_PROF_GEMM_TN2, flops, bytes, s);
     hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)(tiles * g.splits)), dim3(256), T2_LDS_BYTES, s, g);
     CE_LAUNCH_CHECK();
     return 0;

@@ -28,10 +28,12 @@ std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
-const char* kNames[CE_PROF_NCLASS] = {
-    "gemm_nt<BF16>", "gemm_nt<F32>", "gemm_nt<BIAS_BF16>", "gemm_nt<BIAS_F32>", "gemm_nt<BIAS_RESID_F32>",
-    "gemm_nt<BIAS_GELU>", "gemm_nt<GELUGRAD_BF16>", "gemm_tn", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd",
-    "colsum_bf16", "other"};
+const char* kEpi[7] = {"BF16", "F32", "BIAS_BF16", "BIAS_F32", "BIAS_RESID_F32", "BIAS_GELU", "GELUGRAD_BF16"};
+const char* kFam[5] = {"gemm_nt_kernel<%d>", "gemm_nt256_kernel<%d,*,2>", "gemm_nt256_kernel<%d,*,4>", "gemm_nt32_kernel<%d>",
+                       "gemm_nt8_kernel<%d,*,*>"};
+const char* kRest[CE_PROF_NCLASS - CE_PROF_GEMM_TN] = {"gemm_tn3_kernel", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd",
+                                                       "colsum_bf16", "other", "gemm_tn2_kernel"};
+thread_local char g_name[96];
 }  // namespace
 
 int ce_prof_begin(int cls, double flops, double bytes, hipStream_t s) {
@@ -61,7 +63,20 @@ extern "C" void ce_profile_enable(int on) {
 }
 
 extern "C" const char* ce_profile_class_name(int cls) {
-    return (cls >= 0 && cls < CE_PROF_NCLASS) ? kNames[cls] : "?";
+    if (cls < 0 || cls >= CE_PROF_NCLASS) return "?";
+    if (cls >= CE_PROF_GEMM_TN) return kRest[cls - CE_PROF_GEMM_TN];
+    char fam[64];
+    snprintf(fam, sizeof(fam), kFam[cls % 5], cls / 5);
+    snprintf(g_name, sizeof(g_name), "%s %s", fam, kEpi[cls / 5]);       // e.g. "gemm_nt256_kernel<0,*,2> BF16"
+    return g_name;
+}
+
+extern "C" int ce_profile_num_classes(void) { return CE_PROF_NCLASS; }
+
+void ce_prof_retag(int idx, int cls) {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx < (int)g_recs.size()) g_recs[idx].cls = cls;
 }
 
 extern "C" int ce_profile_collect(double* out, int max_classes) {

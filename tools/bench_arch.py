@@ -61,11 +61,12 @@ torch.cuda.synchronize()
 cl.ce_profile_enable(1)
 train_step(model, crit, opt, img, txt, yi, yt, ip)
 torch.cuda.synchronize()
-buf = (ctypes.c_double * (14 * 4))()
-cl.ce_profile_collect(buf, 14)
+NC = int(cl.ce_profile_num_classes())
+buf = (ctypes.c_double * (NC * 4))()
+cl.ce_profile_collect(buf, NC)
 cl.ce_profile_enable(0)
 rows = []
-for c in range(14):
+for c in range(NC):
     cnt, ms, fl, by = buf[c * 4:(c + 1) * 4]
     if cnt > 0:
         rows.append((ms, cl.ce_profile_class_name(c).decode(), cnt, fl / (ms * 1e-3) / 1e12 if ms else 0, by / (ms * 1e-3) / 1e9 if ms else 0))
