@@ -1,5 +1,5 @@
 """RCCL API surface on the real backend with ONE rank (all this one-GPU box allows; the multi-rank semantics are
-proven on gloo in test_distributed_cpu.py and tests/rehearse_ddp.py): every collective the data-parallel path issues
+proven on gloo in test_distributed_cpu.py and, with the HIP model on two ranks, in test_ddp_gpu.py): every collective the data-parallel path issues
 -- all_gather_into_tensor, reduce_scatter_tensor, all_reduce(AVG, async) on slices of the flat gradient buffer from a
 side stream, all_reduce of the loss dict -- exists on "nccl" (= RCCL), accepts our tensors and leaves them unchanged
 at world size 1."""
