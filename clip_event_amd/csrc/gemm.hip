@@ -401,6 +401,7 @@ constexpr int N4_BM = 160, N4_BN = 256, N4_BK = 64, N4_TM = 5;
 constexpr int N4_A_BYTES = N4_BM * N4_BK * 2;                // 20 KiB
 constexpr int N4_STAGE_BYTES = (N4_BM + N4_BN) * N4_BK * 2;   // 52 KiB
 constexpr int N4_LDS_BYTES = 3 * N4_STAGE_BYTES;             // 156 KiB (>= 8 epilogue slices of 17 KiB)
+constexpr int N4_LOADERS = 4;                                // loader waves of gemm_nt160lw_kernel (divides 20 and 32)
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt160_kernel(NTArgs p) {
@@ -509,6 +510,167 @@ __global__ __launch_bounds__(512, 2) void gemm_nt160_kernel(NTArgs p) {
             }
         const int gm0 = m0 + wm * (N4_TM * 16) + mh * 64 + e_r;
         const int its = (N4_TM - mh * 4 >= 4) ? 8 : (N4_TM - mh * 4) * 2;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (it >= its) break;
+            const int m = gm0 + it * 8;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
+            if (m < p.M && gn < p.N) {
+                v0 += bias0;
+                v1 += bias1;
+                nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+            }
+        }
+    }
+    if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        if (p.out2) {
+            float* colsum = reinterpret_cast<float*>(p.out2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    cs0[e] += __shfl_xor(cs0[e], o, 64);
+                    cs1[e] += __shfl_xor(cs1[e], o, 64);
+                }
+            }
+            if (lane < 8 && gn < p.N) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(colsum + gn + e, cs0[e]);
+                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same 160x256x64 tile and three-stage ring with DEDICATED LOADER WAVES: waves 8-11 issue every LDS-DMA
+// instruction (13 each per stage) and wait for them; waves 0-7 only read fragments and issue MFMAs.  In the kernels
+// above each wave spends as long issuing its share of the stage (the CU's one vector-memory path takes 16 cycles per
+// 1 KiB instruction, and all waves queue on it together) as on its 40 MFMAs, and issues no MFMA meanwhile
+// (tools/diag/nt256_stamps.hip); here that queue stalls only waves that have nothing else to do.
+// ------------------------------------------------------------------------------------------
+template <int EPI, int TM>
+__global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160lw_kernel(NTArgs p) {
+    constexpr int BM = 32 * TM;                                   // 160 / 128 / 96 rows
+    constexpr int A_BYTES = BM * N4_BK * 2;
+    constexpr int STAGE_BYTES = (BM + N4_BN) * N4_BK * 2;
+    constexpr int A_INSTR = BM / 8;                               // 20 / 16 / 12 (N4_LOADERS divides each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * N4_BN;
+    const int rowsA = min(p.M - m0, BM), rowsB = min(p.N - n0, N4_BN);
+    const u32x4 rA = make_rsrc_words(p.A + (long)m0 * p.lda, (uint32_t)((long)rowsA * p.lda * 2));
+    const u32x4 rB = make_rsrc_words(p.B + (long)n0 * p.ldb, (uint32_t)((long)rowsB * p.ldb * 2));
+
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem;
+    const int nk = p.K / N4_BK;
+    if (wave >= 8) {
+        // ---- loader waves: all LDS-DMA instructions of a stage (4 TM A + 32 B, 8 rows x 128 B each), TM + 8 per wave.
+        // lane -> row l>>3, LDS position l&7, source chunk = pos ^ (row&7)
+        const int lw = wave - 8;
+        const int s_row = lane >> 3;
+        const int s_chunk = (lane & 7) ^ s_row;
+        const uint32_t vA0 = (uint32_t)((lw * 8 + s_row) * p.lda * 2 + s_chunk * 16);      // A instr = lw + 4 i (i < TM)
+        const uint32_t vB0 = (uint32_t)((lw * 8 + s_row) * p.ldb * 2 + s_chunk * 16);      // B instr = lw + 4 i (i < 8)
+        const uint32_t stepA = (uint32_t)(8 * N4_LOADERS * p.lda * 2), stepB = (uint32_t)(8 * N4_LOADERS * p.ldb * 2);
+        auto stage = [&](int st, int kt) {
+            const uint32_t base = lds0 + st * STAGE_BYTES + lw * 1024;
+            const uint32_t kb = (uint32_t)(kt * N4_BK * 2);
+#pragma unroll
+            for (int i = 0; i < A_INSTR / N4_LOADERS; ++i) dma16_bounds(rA, base + i * (1024 * N4_LOADERS), vA0 + i * stepA + kb);
+#pragma unroll
+            for (int i = 0; i < 32 / N4_LOADERS; ++i) dma16_bounds(rB, base + A_BYTES + i * (1024 * N4_LOADERS), vB0 + i * stepB + kb);
+        };
+        stage(0, 0);
+        if (nk > 1) {
+            stage(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_INSTR + 32) / N4_LOADERS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nxt2 = cur == 0 ? 2 : cur - 1;           // (cur + 2) % 3: read in iteration kt-1, free since its barrier
+            if (kt + 2 < nk) {
+                stage(nxt2, kt + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A_INSTR + 32) / N4_LOADERS) : "memory");   // stage kt+1 landed; kt+2 in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        return;
+    }
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
+    const int fa_base = (wm * (TM * 16) + f_row) * 128;
+    const int fb_base = A_BYTES + (wn * 64 + f_row) * 128;
+
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + f_kc) ^ f_sw) << 4;
+            bf16x8 wf[4], af[TM];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + t * 2048 + coff);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[t][nt], 0, 0, 0);
+        }
+        __syncthreads();                                   // the loaders arrive once stage kt+1 has landed
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+
+    // ---- epilogue through LDS (ring memory is free after the last barrier): per wave 64-row x 64-col fp32 slices
+    constexpr int EROW = 272;
+    char* ebuf = smem + wave * (64 * EROW);
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;
+    const int gn = n0 + wn * 64 + e_c;
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                  EPI == CE_EPI_BIAS_F32) {
+        if (gn < p.N) {
+            bias0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+            bias1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+        }
+    }
+#pragma unroll
+    for (int mh = 0; mh * 4 < TM; ++mh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (mh * 4 + t < TM) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    *reinterpret_cast<f32x4*>(ebuf + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) =
+                        acc[mh * 4 + t][nt];
+            }
+        const int gm0 = m0 + wm * (TM * 16) + mh * 64 + e_r;
+        const int its = (TM - mh * 4 >= 4) ? 8 : (TM - mh * 4) * 2;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             if (it >= its) break;
@@ -1197,9 +1359,15 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160_kernel<EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 5>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
     });
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
-    CeProfScope prof(CE_PROF_GEMM_NT0 + 5 * EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
+    CeProfScope prof(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
     const int force = nt_variant();
     const bool can256 = (a.K % N2_BK == 0) && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo2 % 8 == 0 && a.ldaux % 8 == 0;
     const bool want256 = force == 256 || (force == 0 && a.M >= 1024 && a.N >= 256);
@@ -1219,18 +1387,35 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             }
         }
         const bool use32 = f == 32 || (f == 0 && a.K % N3_BK == 0 && nt32_cost(t5) < best_cost);
-        // Where the cost model picks a 256-column tile with one workgroup per CU, use the 160 x 128 four-wave tile
-        // instead (72 KiB LDS: two workgroups per CU): alone it is no faster, but with the two towers on two streams a
-        // workgroup of the OTHER tower's GEMM can share the CU and fill this one's prologue / epilogue (0.5-2 % on
-        // the step, box dependent), when its tiles fit one resident round (512 slots).  CE_NT_POLICY: bit 0 = that
-        // (default), bit 1 = also instead of the two-workgroup 160x256x32 kernel (slower), bit 2 = pick the tile height
-        // 96..160 by rounds over the 512 slots (slower in the step), bit 3 = also for multi-round launches (noise).
-        static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 1;
+        // Where the cost model picks a 256-column tile with one workgroup per CU and the tiles fit one resident round
+        // (N = width GEMMs: 240 tiles of 160x256), use the loader-wave kernel (gemm_nt160lw_kernel: -2.7 % on the step
+        // against the 160x128 pair below, which was itself 0.5-2 % ahead of the plain 8-wave tile because a workgroup of
+        // the OTHER tower's GEMM could share the CU).  CE_NT_POLICY: bit 0 = treat single-round launches specially
+        // (default), bit 4 = with the loader-wave kernel (default; without it the 160x128 four-wave pair), bit 1 = also
+        // instead of the two-workgroup 160x256x32 kernel (slower), bit 2 = pick the 160x128 family's tile height 96..160 by
+        // rounds over the 512 slots (slower in the step), bit 3 = also for multi-round launches (noise).
+        static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 17;
         const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
         const bool half = f == 104 || (f >= 203 && f <= 205) ||
                           (f == 0 && (half_tiles <= 512 || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
-        prof.retag(CE_PROF_GEMM_NT0 + 5 * EPI + (half || f == 104 ? 1 : (use32 ? 3 : 2)));
-        if (half) {
+        const bool lw = f == 161 || (half && f == 0 && (policy & 16));       // one 160x256 loader-wave workgroup per CU
+        prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + (lw ? 5 : (half || f == 104 ? 1 : (use32 ? 3 : 2))));
+        if (lw) {
+            // shortest tile whose launch still fits one round of the 256 CUs (the text tower's N = 512 has two tile columns)
+            int ltm = 5;
+            static const int lw_tm = getenv("CE_NT_LW_TM") ? atoi(getenv("CE_NT_LW_TM")) : 0;
+            if (lw_tm >= 3 && lw_tm <= 5) ltm = lw_tm;
+            else
+                for (int tm = 4; tm >= 3; --tm)
+                    if ((long)ce_div_up(a.M, 32 * tm) * a.tiles_n <= 256) ltm = tm;
+            a.tiles_m = ce_div_up(a.M, 32 * ltm);
+            const dim3 grid(a.tiles_m * a.tiles_n), block(64 * (8 + N4_LOADERS));
+            switch (ltm) {
+                case 3: hipLaunchKernelGGL((gemm_nt160lw_kernel<EPI, 3>), grid, block, N4_LDS_BYTES, stream, a); break;
+                case 4: hipLaunchKernelGGL((gemm_nt160lw_kernel<EPI, 4>), grid, block, N4_LDS_BYTES, stream, a); break;
+                default: hipLaunchKernelGGL((gemm_nt160lw_kernel<EPI, 5>), grid, block, N4_LDS_BYTES, stream, a); break;
+            }
+        } else if (half) {
             a.tiles_n = ce_div_up(a.N, 128);
             int htm = 5;
             if (f >= 203 && f <= 205) htm = f - 200;

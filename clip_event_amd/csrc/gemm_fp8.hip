@@ -242,7 +242,7 @@ int g_force8 = 0;     // tools: 0 auto, 4/5/6/8 = tile height of the 256-column 
 template <int EPI>
 int launch_nt8(NTArgs a, hipStream_t stream) {
     const double out_b = EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0);
-    CeProfScope prof(CE_PROF_GEMM_NT0 + 5 * EPI + 4, 2.0 * a.M * a.N * a.K, 1.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
+    CeProfScope prof(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 4, 2.0 * a.M * a.N * a.K, 1.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
     // tile choice as in gemm.hip: rounds over the 256 CUs x cost of a round; the two-workgroup 160x128 tile when its
     // tiles fit one resident round
     const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
