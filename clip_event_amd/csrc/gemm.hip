@@ -1273,6 +1273,146 @@ __global__ __launch_bounds__(1024, 4) void gemm_tn3_kernel(TNGroup grp) {
 }
 
 // ------------------------------------------------------------------------------------------
+// TN kernel v3 with LOADER WAVES: the same tile, ring and LDS images; 8 compute waves of 128 (n) x 64 (k) outputs
+// (4 x 2 v_mfma_f32_32x32x16_bf16: a quarter fewer fragment reads per FLOP than 64x64) + 4 loader waves, one per image,
+// that issue and wait for every LDS-DMA instruction (a workgroup is limited to 16 waves, so 16 compute waves leave
+// no room for loaders).  The compute waves only wait at the stage barrier.
+// ------------------------------------------------------------------------------------------
+template <int T3_ROWS, int T3_STAGES>
+__global__ __launch_bounds__(768, 3) void gemm_tn3lw_kernel(TNGroup grp) {
+    constexpr int T3_IMG_BYTES = T3_ROWS * 256;
+    constexpr int T3_STAGE_BYTES = 4 * T3_IMG_BYTES;
+    constexpr int KSTEPS = T3_ROWS / 16;                  // 16-row MFMA k-steps per stage
+    constexpr int DPL = T3_ROWS / 4;                      // DMA instructions per LOADER wave and stage: one image, 4 rows x 256 B each
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = (wave >> 2) & 1, wk = wave & 3;        // compute waves 0-7: 128 (n) x 64 (k) each; waves 8-11 load
+
+    const int m_tiles = (grp.M + TN_BM - 1) / TN_BM;
+    const int mps = grp.m_per_split / TN_BM;
+    const int s_r = lane >> 4;
+    const int s_chunk = (lane & 15) ^ (s_r << 2);
+    const int g = lane >> 4, li = lane & 15;
+    const int t_row = 8 * (g >> 1) + (li >> 2);
+    const int t_sw = (li >> 2) << 2;
+    const int t_cb = 2 * (g & 1) + ((li & 3) >> 1);
+    int offP[4], offQ[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        offP[t] = wn * T3_IMG_BYTES + t_row * 256 + (((t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        offQ[t] = (2 + (wk >> 1)) * T3_IMG_BYTES + t_row * 256 + ((((wk & 1) * 8 + t * 4 + t_cb) ^ t_sw) << 4) + (li & 1) * 8;
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    int tile = lb / grp.splits;
+    const int mt0 = (lb - tile * grp.splits) * mps;
+    const int mt1 = min(m_tiles, mt0 + mps);
+    if (mt0 >= mt1) return;  // uniform per block
+    int pi = 0;
+    while (pi + 1 < grp.count && tile >= grp.tile_end[pi]) ++pi;   // block-uniform
+    if (pi > 0) tile -= grp.tile_end[pi - 1];
+    const TNArgs& p = grp.prob[pi];
+    int tn, tk;
+    {
+        constexpr int BNB = 2, BKB = 2;      // 2x2 blocks of 256^2 tiles = the panel sharing of v2's 4x4 blocks
+        const int br = tile / (BNB * p.tiles_k);
+        const int r0 = br * BNB, rows_b = min(BNB, p.tiles_n - r0);
+        const int t1 = tile - br * BNB * p.tiles_k;
+        const int bc = t1 / (rows_b * BKB);
+        const int c0 = bc * BKB, cols_b = min(BKB, p.tiles_k - c0);
+        const int t2 = t1 - bc * rows_b * BKB;
+        tn = r0 + t2 / cols_b;
+        tk = c0 + t2 % cols_b;
+    }
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int ms = mt0 * TN_BM;
+    const int rows = min(grp.M, mt1 * TN_BM) - ms;
+
+    const int nst = (rows + T3_ROWS - 1) / T3_ROWS;
+    const int D = min(grp.depth, T3_STAGES - 1);           // stages issued ahead of the one being multiplied
+    if (wave >= 8) {
+        // ---- loader wave: image wave-8 (P0 P1 Q0 Q1) of every stage, DPL instructions of 4 rows x 256 B
+        const int img = wave - 8;
+        const bool isP = img < 2;
+        const long ld = isP ? p.ldp : p.ldq;
+        const bf16_t* src = isP ? p.P : p.Q;
+        const int col0 = (isP ? n0 : k0) + 128 * (img & 1);
+        const u32x4 rsrc = make_rsrc_words(src + (long)ms * ld, (uint32_t)((long)rows * ld * 2));
+        const uint32_t vo0 = (uint32_t)(s_r * ld * 2 + (col0 + s_chunk * 8) * 2);
+        const uint32_t vstep = (uint32_t)(4 * ld * 2);
+        const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem + img * T3_IMG_BYTES;
+        auto stage = [&](int slot, int st) {
+            const uint32_t d = lds0 + slot * T3_STAGE_BYTES;
+            const uint32_t mb = (uint32_t)((long)st * T3_ROWS * ld * 2);
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) dma16_bounds(rsrc, d + j * 1024, vo0 + j * vstep + mb);
+        };
+        stage(0, 0);
+        if (nst > 1 && D > 1) stage(1, 1);
+        if (nst > 2 && D > 2) stage(2, 2);
+        int slot = 0;
+        for (int i = 0; i < nst; ++i) {
+            const int later = min(nst - 1 - i, D - 1);         // stages i+1 .. issued and not yet needed
+            if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPL) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // stage i published; stage i-1 has been read by every compute wave
+            if (i + D < nst) {
+                int sl = slot + D;
+                if (sl >= T3_STAGES) sl -= T3_STAGES;
+                stage(sl, i + D);
+            }
+            slot = slot + 1 == T3_STAGES ? 0 : slot + 1;
+        }
+        return;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[nt][0][r] = 0.f; acc[nt][1][r] = 0.f;
+        }
+    int slot = 0;
+    for (int i = 0; i < nst; ++i) {
+        __builtin_amdgcn_s_barrier();
+        const char* st = smem + slot * T3_STAGE_BYTES;
+        slot = slot + 1 == T3_STAGES ? 0 : slot + 1;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 qf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) qf[t] = tr_frag2(st + offQ[t] + s * 16 * 256);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16x8 pf = tr_frag2(st + offP[nt] + s * 16 * 256);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qf[kt], acc[nt][kt], 0, 0, 0);
+            }
+        }
+    }
+
+    const int ek = k0 + wk * 64 + (lane & 31);
+    const int en = n0 + wn * 128 + 4 * (lane >> 5);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k = ek + kt * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+                atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // probes: raw fragment in / raw accumulator out, so the host can check the lane maps
 // ------------------------------------------------------------------------------------------
 __global__ void probe_mfma16_kernel(const bf16x8* a, const bf16x8* b, f32x4* out) {
@@ -1537,6 +1677,10 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
                             4 * 32 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_kernel<48, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             3 * 48 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3lw_kernel<48, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            3 * 48 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3lw_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * 32 * 1024);
         const char* e = getenv("CE_GEMM_TN");
         if (e) variant = atoi(e);
     });
@@ -1622,7 +1766,12 @@ extern "C" int ce_gemm_tn_grouped(int count, const void* const* P, const long* l
         // 48-row stages x 3 slots (default; in the step 993 TF/s) or 32-row stages x 4 slots (CE_TN3_ROWS=32: 935): one
         // stage less in flight costs nothing (prefetch depth 2 = depth 3 above), a third fewer barriers per FLOP pays
         static int rows48 = getenv("CE_TN3_ROWS") ? atoi(getenv("CE_TN3_ROWS")) != 32 : 1;
-        if (rows48)
+        static int lw = getenv("CE_TN3_LW") ? atoi(getenv("CE_TN3_LW")) : 1;   // loader-wave form: 1127 -> 1188 TF/s in the step
+        if (lw && rows48)
+            hipLaunchKernelGGL((gemm_tn3lw_kernel<48, 3>), dim3((unsigned)(tiles3 * g.splits)), dim3(768), 3 * 48 * 1024, s, g);
+        else if (lw)
+            hipLaunchKernelGGL((gemm_tn3lw_kernel<32, 4>), dim3((unsigned)(tiles3 * g.splits)), dim3(768), 4 * 32 * 1024, s, g);
+        else if (rows48)
             hipLaunchKernelGGL((gemm_tn3_kernel<48, 3>), dim3((unsigned)(tiles3 * g.splits)), dim3(1024), 3 * 48 * 1024, s, g);
         else
             hipLaunchKernelGGL((gemm_tn3_kernel<32, 4>), dim3((unsigned)(tiles3 * g.splits)), dim3(1024), 4 * 32 * 1024, s, g);

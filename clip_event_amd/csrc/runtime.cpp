@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -64,6 +65,10 @@ extern "C" void ce_profile_enable(int on) {
 
 extern "C" const char* ce_profile_class_name(int cls) {
     if (cls < 0 || cls >= CE_PROF_NCLASS) return "?";
+    if (cls == CE_PROF_GEMM_TN) {      // the rocprofv3 row of whichever 256x256 form the launcher uses (csrc/gemm.hip)
+        static const bool lw = getenv("CE_TN3_LW") ? atoi(getenv("CE_TN3_LW")) != 0 : true;
+        return lw ? "gemm_tn3lw_kernel" : "gemm_tn3_kernel";
+    }
     if (cls >= CE_PROF_GEMM_TN) return kRest[cls - CE_PROF_GEMM_TN];
     char fam[64];
     snprintf(fam, sizeof(fam), kFam[cls % CE_PROF_NT_FAMILIES], cls / CE_PROF_NT_FAMILIES);

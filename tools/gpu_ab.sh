@@ -11,7 +11,7 @@ import json, sys
 d = json.load(open(sys.argv[2]))
 r = d["roofline"]
 cls = {c["kernel"]: c for c in r["classes"]}
-tn = cls.get("gemm_tn3_kernel", cls.get("gemm_tn", {}))
+tn = cls.get("gemm_tn3lw_kernel", cls.get("gemm_tn3_kernel", cls.get("gemm_tn", {})))
 print(f"{sys.argv[1]:40s} {d['ms_per_step']:7.3f} ms/step  tn {tn.get('ms_per_step', 0):.3f} ms ({tn.get('tflops', 0):.0f} TF, {tn.get('launches_per_step', 0):.0f} launches)  "
       f"sum_classes {sum(c['ms_per_step'] for c in r['classes']):.2f} ms")
 PY
