@@ -707,6 +707,197 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160lw_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// PERSISTENT loader-wave kernel for launches of several rounds of tiles (N = 3d, 4d): one workgroup per CU walks its
+// tiles (xb, xb + grid, ...); the ring, the barrier protocol and the stage count per loader never stop at a tile edge, so
+// the loaders fetch the next tile's first two stages while the compute waves are in the epilogue of the current one, and
+// that epilogue's stores drain under the next tile's MFMAs.  The epilogue transposes 16-row chunks through the ring slot
+// of the tile's LAST stage (free until the barrier that opens the next tile's first iteration; one extra barrier per
+// tile makes sure every wave has finished reading it).  Needs K >= 128.
+// ------------------------------------------------------------------------------------------
+template <int EPI, int TM>
+__global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(NTArgs p) {
+    constexpr int BM = 32 * TM;
+    constexpr int A_BYTES = BM * N4_BK * 2;
+    constexpr int STAGE_BYTES = (BM + N4_BN) * N4_BK * 2;
+    constexpr int A_INSTR = BM / 8;
+    constexpr int PER = (A_INSTR + 32) / N4_LOADERS;              // LDS-DMA instructions per loader wave and stage
+    constexpr bool PF_AUX = EPI == CE_EPI_GELUGRAD_BF16;
+    constexpr int NPQ = 2 * TM > 8 ? 6 : 2 * TM;                  // 8-row slots prefetched (what the 168-VGPR budget holds)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;                                      // <= total
+    const int xb = xcd_remap(blockIdx.x, G);
+    const int n_my = (total - xb + G - 1) / G;                    // this workgroup's tiles: xb + t * G
+    const int nk = p.K / N4_BK;                                   // >= 2
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem;
+
+    if (wave >= 8) {
+        // ---- loader waves: instruction j = lw + N4_LOADERS * i of a stage (8 rows x 128 B each; A_INSTR of A, then 32 of B)
+        const int lw = wave - 8;
+        const int s_row = lane >> 3;
+        const int s_chunk = (lane & 7) ^ s_row;
+        const uint32_t vA0 = (uint32_t)((lw * 8 + s_row) * p.lda * 2 + s_chunk * 16);
+        const uint32_t vB0 = (uint32_t)((lw * 8 + s_row) * p.ldb * 2 + s_chunk * 16);
+        const uint32_t stepA = (uint32_t)(8 * N4_LOADERS * p.lda * 2), stepB = (uint32_t)(8 * N4_LOADERS * p.ldb * 2);
+        auto desc = [&](int t, u32x4& rA, u32x4& rB) {
+            const int tile = xb + t * G;
+            const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+            const int m0 = tm * BM, n0 = tn * N4_BN;
+            rA = make_rsrc_words(p.A + (long)m0 * p.lda, (uint32_t)((long)min(p.M - m0, BM) * p.lda * 2));
+            rB = make_rsrc_words(p.B + (long)n0 * p.ldb, (uint32_t)((long)min(p.N - n0, N4_BN) * p.ldb * 2));
+        };
+        auto issue = [&](const u32x4& rA, const u32x4& rB, int slot, int kt) {
+            const uint32_t base = lds0 + slot * STAGE_BYTES + lw * 1024;
+            const uint32_t kb = (uint32_t)(kt * N4_BK * 2);
+#pragma unroll
+            for (int i = 0; i < A_INSTR / N4_LOADERS; ++i) dma16_bounds(rA, base + i * (1024 * N4_LOADERS), vA0 + i * stepA + kb);
+#pragma unroll
+            for (int i = 0; i < 32 / N4_LOADERS; ++i) dma16_bounds(rB, base + A_BYTES + i * (1024 * N4_LOADERS), vB0 + i * stepB + kb);
+        };
+        u32x4 rA, rB, rA2, rB2;
+        desc(0, rA, rB);
+        rA2 = rA; rB2 = rB;
+        issue(rA, rB, 0, 0);
+        issue(rA, rB, 1, 1);
+        int slot = 0;                                             // ring slot of the stage the compute waves multiply next
+        for (int t = 0; t < n_my; ++t) {
+            const bool has_next = t + 1 < n_my;
+            if (has_next) desc(t + 1, rA2, rB2);
+            for (int kt = 0; kt < nk; ++kt) {
+                // this wave's part of stage (t, kt) has landed; the following stage (issued already) may be in flight
+                if (kt + 1 < nk || has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                  // publishes the stage; the previous one has been read
+                const int s2 = slot == 0 ? 2 : slot - 1;          // its slot takes the stage two ahead
+                if (kt + 2 < nk) issue(rA, rB, s2, kt + 2);
+                else if (has_next) issue(rA2, rB2, s2, kt + 2 - nk);
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            __syncthreads();                                      // the tile's last stage has been read: its slot is epilogue scratch
+            rA = rA2; rB = rB2;
+        }
+        return;
+    }
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
+    const int fa_base = (wm * (TM * 16) + f_row) * 128;
+    const int fb_base = A_BYTES + (wn * 64 + f_row) * 128;
+    constexpr int EROW = 272;
+    const int e_r = lane >> 3, e_c = (lane & 7) * 8;
+    int slot = 0;
+    for (int t = 0; t < n_my; ++t) {
+        const int tile = xb + t * G;
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+        const int m0 = tm * BM, n0 = tn * N4_BN;
+        f32x4 acc[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int last = slot;
+        auto k_iter = [&]() __attribute__((always_inline)) {
+            __syncthreads();
+            const char* st = smem + slot * STAGE_BYTES;
+            last = slot;
+            slot = slot == 2 ? 0 : slot + 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((ks * 4 + f_kc) ^ f_sw) << 4;
+                bf16x8 wf[4], af[TM];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + fb_base + i * 2048 + coff);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + fa_base + i * 2048 + coff);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[i], acc[i][nt], 0, 0, 0);
+            }
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) k_iter();
+        // GELUGRAD: the bf16 pre-activation tile (16 B per lane and 8-row slot) comes into registers under the last K
+        // iteration instead of inside the epilogue, where nothing else on the CU would cover its latency
+        const int gn = n0 + wn * 64 + e_c;
+        u32x4 ap[PF_AUX ? NPQ : 1];
+        if constexpr (PF_AUX) {
+#pragma unroll
+            for (int q = 0; q < NPQ; ++q) {
+                const int m = m0 + wm * (TM * 16) + q * 8 + e_r;
+                ap[q] = (m < p.M && gn < p.N) ? *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + gn) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        k_iter();
+        __syncthreads();
+
+        // ---- epilogue: 16 rows x 64 columns at a time through this wave's 4.25 KiB of the free slot
+        char* ebuf = smem + last * STAGE_BYTES + wave * (16 * EROW);
+        f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                      EPI == CE_EPI_BIAS_F32) {
+            if (gn < p.N) {
+                bias0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+                bias1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(ebuf + (lane & 15) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) = acc[i][nt];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int m = m0 + wm * (TM * 16) + i * 16 + it * 8 + e_r;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + (it * 8 + e_r) * EROW + e_c * 4 + 16);
+                if (m < p.M && gn < p.N) {
+                    v0 += bias0;
+                    v1 += bias1;
+                    if (PF_AUX && i * 2 + it < NPQ) {
+                        const u32x4 a = ap[i * 2 + it < NPQ ? i * 2 + it : 0];
+                        f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
+                                    v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
+                        f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
+                                    v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
+                        cs0 += r0;
+                        cs1 += r1;
+                        u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + gn) = o;
+                    } else {
+                        nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+            if (p.out2) {
+                float* colsum = reinterpret_cast<float*>(p.out2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        cs0[e] += __shfl_xor(cs0[e], o, 64);
+                        cs1[e] += __shfl_xor(cs1[e], o, 64);
+                    }
+                }
+                // after the reduction every lane holds the sums of its 8 columns; lane l adds element l>>3 of them, so the
+                // wave's 64 columns go out in ONE atomic instruction (eight 8-lane instructions per wave and tile cost
+                // ~3 us per tile at the chip's float-atomic rate)
+                const int e = lane >> 3;
+                const float v = e == 0 ? cs0[0] : e == 1 ? cs0[1] : e == 2 ? cs0[2] : e == 3 ? cs0[3]
+                              : e == 4 ? cs1[0] : e == 5 ? cs1[1] : e == 6 ? cs1[2] : cs1[3];
+                if (gn + e < p.N) atomicAdd(colsum + gn + e, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // NT kernel, 160x256x32 tile, 8 waves, SMALL footprint: 2 x 26 KiB LDS stages and <= 128 VGPRs, so two
 // (even three) workgroups share a CU and one workgroup's epilogue / prologue overlaps another's MFMA loop.
 // Used for the GEMMs that need several rounds of tiles (N = 3d, 4d); per-tile prologue+epilogue is ~40 % of
@@ -1505,6 +1696,12 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
     });
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 ? 4.0 : 2.0));
     CeProfScope prof(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
@@ -1531,7 +1728,8 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         // (N = width GEMMs: 240 tiles of 160x256), use the loader-wave kernel (gemm_nt160lw_kernel: -2.7 % on the step
         // against the 160x128 pair below, which was itself 0.5-2 % ahead of the plain 8-wave tile because a workgroup of
         // the OTHER tower's GEMM could share the CU).  CE_NT_POLICY: bit 0 = treat single-round launches specially
-        // (default), bit 4 = with the loader-wave kernel (default; without it the 160x128 four-wave pair), bit 1 = also
+        // (default), bit 4 = with the loader-wave kernel (default; without it the 160x128 four-wave pair), bits 5, 6 = the
+        // persistent loader-wave kernel for multi-round launches (below; off), bit 1 = also
         // instead of the two-workgroup 160x256x32 kernel (slower), bit 2 = pick the 160x128 family's tile height 96..160 by
         // rounds over the 512 slots (slower in the step), bit 3 = also for multi-round launches (noise).
         static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 17;
@@ -1540,7 +1738,35 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                           (f == 0 && (half_tiles <= 512 || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
         const bool lw = f == 161 || (half && f == 0 && (policy & 16));       // one 160x256 loader-wave workgroup per CU
         prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + (lw ? 5 : (half || f == 104 ? 1 : (use32 ? 3 : 2))));
-        if (lw) {
+        // multi-round launches: the persistent loader-wave kernel, OFF by default.  Bit 5 = for the light epilogues (qkv
+        // forward: 726 -> 812 TF/s as a kernel, but the step does not move: 14.04 / 14.28 ms without, 14.41 / 14.22 with --
+        // a grid that holds every CU for its whole run leaves the other tower's stream nothing to overlap); bit 6 = also
+        // for the GELU epilogues, where it loses to the two-workgroup 160x256x32 kernel even as a kernel (509 vs 560 TF/s)
+        constexpr bool light_epi = EPI == CE_EPI_BF16 || EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_F32;
+        const bool pers = !lw && a.K >= 2 * N4_BK && ((f >= 163 && f <= 165) || f == 162 ||
+                                                     (f == 0 && !half && ((policy & 32) && light_epi || (policy & 64))));
+        if (pers) {
+            // tile height by the longest per-CU tile list: rows of tile work + ~48 rows' worth of epilogue per tile
+            int ptm = 5;
+            if (f >= 163 && f <= 165) ptm = f - 160;
+            else {
+                long bc = -1;
+                for (int tm = 5; tm >= 3; --tm) {
+                    const long tiles = (long)ce_div_up(a.M, 32 * tm) * a.tiles_n;
+                    const long cost = ((tiles + 255) / 256) * (32 * tm + 48);
+                    if (bc < 0 || cost < bc) { bc = cost; ptm = tm; }
+                }
+            }
+            a.tiles_m = ce_div_up(a.M, 32 * ptm);
+            const long tiles = (long)a.tiles_m * a.tiles_n;
+            const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(64 * (8 + N4_LOADERS));
+            prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 5);
+            switch (ptm) {
+                case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3>), grid, block, N4_LDS_BYTES, stream, a); break;
+                case 4: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4>), grid, block, N4_LDS_BYTES, stream, a); break;
+                default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5>), grid, block, N4_LDS_BYTES, stream, a); break;
+            }
+        } else if (lw) {
             // shortest tile whose launch still fits one round of the 256 CUs (the text tower's N = 512 has two tile columns)
             int ltm = 5;
             static const int lw_tm = getenv("CE_NT_LW_TM") ? atoi(getenv("CE_NT_LW_TM")) : 0;

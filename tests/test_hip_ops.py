@@ -75,6 +75,42 @@ def test_gemm_nt_epilogues(M, N, K):
     assert _report("gelugrad colsum", colsum.cpu(), want.sum(0))[1] < 3e-3
 
 
+@pytest.mark.parametrize("variant", [5, 8, 32, 104, 160, 161, 162, 163, 164])
+def test_gemm_nt_forced_tile_variants(variant):
+    """Every NT tile family forced through ce_gemm_nt_tune (the per-shape policy reaches only some of them at test sizes):
+    8-wave 256-column tiles (5, 8), 160x256x32 pairs (32), 160x128 pairs (104), three-stage ring (160), loader waves
+    single-round (161) and persistent at tile heights chosen / 96 / 128 rows (162-164); ragged M and N edges, K = 3 tiles,
+    the epilogues with extra operands."""
+    from clip_event_amd import ops, _lib as L
+    M, N, K = 2900, 1032, 192
+    rng = np.random.default_rng(variant)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    bias, resid, aux = _randn(rng, N), _randn(rng, M, N), _randn(rng, M, N).to(torch.bfloat16)
+    acc = a.float() @ b.float().t()
+    A, B = a.to(DEV), b.to(DEV)
+    lib = L.lib()
+    lib.ce_gemm_nt_tune(variant)
+    try:
+        o = ops.gemm_nt(A, B, L.EPI_F32).cpu()
+        assert _report(f"v{variant} f32", o, acc)[1] < 1e-5
+        o = ops.gemm_nt(A, B, L.EPI_BIAS_RESID_F32, bias=bias.to(DEV), resid=resid.to(DEV)).cpu()
+        assert _report(f"v{variant} bias_resid", o, acc + bias + resid)[1] < 1e-5
+        pre, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+        h = acc + bias
+        assert _report(f"v{variant} gelu pre", pre.float().cpu(), h)[1] < 3e-3
+        assert _report(f"v{variant} gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
+        colsum = torch.zeros(N, device=DEV)
+        o = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV), out2=colsum).float().cpu()
+        x = aux.float()
+        sg = torch.sigmoid(1.702 * x)
+        want = acc * (sg * (1 + 1.702 * x * (1 - sg)))
+        assert _report(f"v{variant} gelugrad", o, want)[1] < 3e-3
+        assert _report(f"v{variant} colsum", colsum.cpu(), want.sum(0))[1] < 3e-3
+    finally:
+        lib.ce_gemm_nt_tune(0)
+
+
 TN_SHAPES = [(64, 128, 128), (256, 256, 384), (1000, 768, 512), (77 * 8, 512, 2048), (50, 64, 72), (12800, 768, 768),
              (4096, 512, 2048), (2120, 256, 256), (11137, 2048, 512)]      # the last three: the 256x256-tile kernel, ragged M
 
