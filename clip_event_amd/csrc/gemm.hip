@@ -28,6 +28,10 @@
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
+#ifndef CE_DIAG_TN3
+#define CE_DIAG_TN3 0
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -1539,7 +1543,12 @@ __global__ __launch_bounds__(768, 3) void gemm_tn3lw_kernel(TNGroup grp) {
             const uint32_t d = lds0 + slot * T3_STAGE_BYTES;
             const uint32_t mb = (uint32_t)((long)st * T3_ROWS * ld * 2);
 #pragma unroll
-            for (int j = 0; j < DPL; ++j) dma16_bounds(rsrc, d + j * 1024, vo0 + j * vstep + mb);
+            for (int j = 0; j < DPL; ++j) {
+#if CE_DIAG_TN3 == 2      // ablation build (tools/diag/tn3_ablate.sh): no operand traffic
+                if (p.ldo < 0)
+#endif
+                dma16_bounds(rsrc, d + j * 1024, vo0 + j * vstep + mb);
+            }
         };
         stage(0, 0);
         if (nst > 1 && D > 1) stage(1, 1);
@@ -1598,6 +1607,9 @@ __global__ __launch_bounds__(768, 3) void gemm_tn3lw_kernel(TNGroup grp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = en + nt * 32 + (r & 3) + 8 * (r >> 2);
+#if CE_DIAG_TN3 == 1      // ablation build: no epilogue traffic (the condition keeps the MFMAs alive)
+                if (acc[nt][kt][r] == 12345.678f)
+#endif
                 atomicAdd(p.out + (long)n * p.ldo + k, acc[nt][kt][r]);
             }
         }

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
 from ctypes import c_int, c_long, c_void_p
 import torch
+import clip_event_amd._lib as _L
+if os.environ.get("CE_DIAG_LIB"):          # tools/diag/tn3_ablate.sh: an ablation build of the library
+    _L.LIB_PATH = os.environ["CE_DIAG_LIB"]
 from clip_event_amd._lib import check, lib, stream
 
 DEV = "cuda:0"
