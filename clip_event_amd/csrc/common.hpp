@@ -91,10 +91,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: `/` without fast-math is a ten-instruction sequence, and in the GEMM
+// epilogues that apply these to every output element it was most of the epilogue (12.5k of a K = 768 tile's 35k cycles,
+// tools/diag/make_nt160p_stamps.py); the results are rounded to bf16 afterwards.
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 // d/dx [x * sigmoid(1.702 x)] = s + 1.702 x s (1 - s)
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 

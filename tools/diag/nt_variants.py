@@ -10,6 +10,7 @@ from clip_event_amd import ops, _lib as L
 
 DEV = "cuda:0"
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,104,5,160,161,32").split(",")]
+EPI = int(os.environ.get("EPI", "0"))          # 0 BF16, 2 BIAS_BF16, 4 BIAS_RESID_F32, 5 BIAS_GELU, 6 GELUGRAD_BF16
 
 
 def timeit(fn, pre=None, iters=20, warm=3):
@@ -41,17 +42,26 @@ def main():
         b = (torch.randn(N, K, device=DEV) * K ** -0.5).to(torch.bfloat16)
         ref = None
         row = []
+        bias = torch.randn(N, device=DEV)
+        resid = torch.randn(M, N, device=DEV) if EPI == 4 else None
+        aux = torch.randn(M, N, device=DEV).to(torch.bfloat16) if EPI == 6 else None
+        colsum = torch.zeros(N, device=DEV) if EPI == 6 else None
         for v in VARIANTS:
             lib.ce_gemm_nt_tune(v)
-            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-            ops.gemm_nt(a, b, L.EPI_BF16, out=out)
+            out = torch.empty(M, N, device=DEV, dtype=torch.float32 if EPI == 4 else torch.bfloat16)
+            out2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16) if EPI == 5 else colsum
+
+            def run():
+                return ops.gemm_nt(a, b, EPI, bias=bias if EPI in (2, 4, 5) else None, resid=resid, aux=aux, out=out, out2=out2)
+
+            run()
             if ref is None:
-                ref = out.float()
+                ref = out.float().clone()
             else:
                 err = (out.float() - ref).abs().max().item()
                 assert err < 2e-2 * ref.abs().max().item(), (v, M, N, K, err)
-            w = timeit(lambda: ops.gemm_nt(a, b, L.EPI_BF16, out=out))
-            c = timeit(lambda: ops.gemm_nt(a, b, L.EPI_BF16, out=out), pre=lambda: junk.fill_(1.0))
+            w = timeit(run)
+            c = timeit(run, pre=lambda: junk.fill_(1.0))
             row.append((w, c))
         lib.ce_gemm_nt_tune(0)
         print(f"M={M:6d} N={N:5d} K={K:5d}".ljust(28) + "".join(f"{w:7.1f}/{c:6.1f}" for w, c in row), flush=True)
