@@ -538,13 +538,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt160_kernel(NTArgs p) {
                     cs1[e] += __shfl_xor(cs1[e], o, 64);
                 }
             }
-            if (lane < 8 && gn < p.N) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(colsum + gn + e, cs0[e]);
-                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
-                }
-            }
+            const int e = lane >> 3;      // lane l adds element l>>3 of its 8 column sums: the wave's 64 columns in one instruction
+            const float v = e == 0 ? cs0[0] : e == 1 ? cs0[1] : e == 2 ? cs0[2] : e == 3 ? cs0[3]
+                          : e == 4 ? cs1[0] : e == 5 ? cs1[1] : e == 6 ? cs1[2] : cs1[3];
+            if (gn + e < p.N) atomicAdd(colsum + gn + e, v);
         }
     }
 }
@@ -699,13 +696,10 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160lw_kernel(
                     cs1[e] += __shfl_xor(cs1[e], o, 64);
                 }
             }
-            if (lane < 8 && gn < p.N) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(colsum + gn + e, cs0[e]);
-                    atomicAdd(colsum + gn + 4 + e, cs1[e]);
-                }
-            }
+            const int e = lane >> 3;      // lane l adds element l>>3 of its 8 column sums: the wave's 64 columns in one instruction
+            const float v = e == 0 ? cs0[0] : e == 1 ? cs0[1] : e == 2 ? cs0[2] : e == 3 ? cs0[3]
+                          : e == 4 ? cs1[0] : e == 5 ? cs1[1] : e == 6 ? cs1[2] : cs1[3];
+            if (gn + e < p.N) atomicAdd(colsum + gn + e, v);
         }
     }
 }
