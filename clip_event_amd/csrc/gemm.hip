@@ -144,6 +144,117 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// SKINNY NT kernel for the few-row GEMMs (M <= 512: the pruned last block's 256 rows, the feature projections): the
+// tile grid of such a problem is 12-48 tiles for 256 CUs and each tile's K loop is a chain of exposed latencies, so the
+// parallelism has to come from K.  A workgroup owns a 64 x 64 output tile; its 8 waves each take an eighth of K, with
+// both operands read from global memory straight into MFMA fragments (K-contiguous rows: a lane's 8 contraction values
+// are one 16-byte load; no LDS staging, next k-step's fragments in flight during the MFMAs), and the eight partial tiles
+// are summed through LDS before the fused epilogue.  No atomics, no scratch, one launch.
+// ------------------------------------------------------------------------------------------
+constexpr int SK_LDS_BYTES = 8 * 64 * 272;
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_skinny_kernel(NTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int kw = p.K >> 3;                              // this wave's K slice (a multiple of 32)
+    const int nks = kw >> 5;
+    const int f_row = lane & 15, f_k = (lane >> 4) * 8;
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                        // rows past the edge are clamped: their products are never stored
+        pa[t] = p.A + (long)min(m0 + t * 16 + f_row, p.M - 1) * p.lda + wave * kw + f_k;
+        pb[t] = p.B + (long)min(n0 + t * 16 + f_row, p.N - 1) * p.ldb + wave * kw + f_k;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][4], wf[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        af[0][t] = *reinterpret_cast<const bf16x8*>(pa[t]);
+        wf[0][t] = *reinterpret_cast<const bf16x8*>(pb[t]);
+    }
+    for (int ks = 0; ks < nks; ks += 2) {
+        if (ks + 1 < nks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[1][t] = *reinterpret_cast<const bf16x8*>(pa[t] + (ks + 1) * 32);
+                wf[1][t] = *reinterpret_cast<const bf16x8*>(pb[t] + (ks + 1) * 32);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], af[0][t], acc[t][nt], 0, 0, 0);
+        if (ks + 1 < nks) {
+            if (ks + 2 < nks) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[0][t] = *reinterpret_cast<const bf16x8*>(pa[t] + (ks + 2) * 32);
+                    wf[0][t] = *reinterpret_cast<const bf16x8*>(pb[t] + (ks + 2) * 32);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][nt], af[1][t], acc[t][nt], 0, 0, 0);
+        }
+    }
+    // partial tiles -> LDS ([wave][64 rows][64 cols] fp32, 272-byte rows); lane holds row t*16 + (lane&15), cols nt*16 + 4*(lane>>4) ..
+    constexpr int EROW = 272;
+    char* mine = smem + wave * (64 * EROW);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            *reinterpret_cast<f32x4*>(mine + (t * 16 + (lane & 15)) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) = acc[t][nt];
+    __syncthreads();
+    const int e_r = tid >> 3, e_c = (tid & 7) * 8;        // 512 threads x 8 columns = the 64 x 64 tile
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        v0 += *reinterpret_cast<const f32x4*>(smem + w * (64 * EROW) + e_r * EROW + e_c * 4);
+        v1 += *reinterpret_cast<const f32x4*>(smem + w * (64 * EROW) + e_r * EROW + e_c * 4 + 16);
+    }
+    const int m = m0 + e_r, gn = n0 + e_c;
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    if (m < p.M && gn < p.N) {
+        if constexpr (EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_RESID_F32 || EPI == CE_EPI_BIAS_GELU ||
+                      EPI == CE_EPI_BIAS_F32) {
+            v0 += *reinterpret_cast<const f32x4*>(p.bias + gn);
+            v1 += *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+        }
+        nt_epilogue8<EPI>(p, m, gn, v0, v1, cs0, cs1);
+    }
+    if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
+        if (p.out2) {        // column sums over this wave's 8 rows (lanes with equal lane&7 share columns), then one atomic per lane
+            float* colsum = reinterpret_cast<float*>(p.out2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    cs0[e] += __shfl_xor(cs0[e], o, 64);
+                    cs1[e] += __shfl_xor(cs1[e], o, 64);
+                }
+            }
+            const int e = lane >> 3;
+            const float v = e == 0 ? cs0[0] : e == 1 ? cs0[1] : e == 2 ? cs0[2] : e == 3 ? cs0[3]
+                          : e == 4 ? cs1[0] : e == 5 ? cs1[1] : e == 6 ? cs1[2] : cs1[3];
+            if (gn + e < p.N) atomicAdd(colsum + gn + e, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // NT kernel, 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), operands staged straight
 // into LDS by global_load_lds (LDS-DMA, 16 B per lane): no VGPR round trip and no ds_write
 // issue cost, which is what bounds the 128^2 register-staged kernel.  The DMA destination is
@@ -1825,6 +1936,17 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                 default: launch_nt256<EPI, 8>(a, stream); break;
             }
         }
+    } else if (static const int skinny = getenv("CE_NT_SKINNY") ? atoi(getenv("CE_NT_SKINNY")) : 1;
+               skinny && force == 0 && a.M <= 512 && a.K % 256 == 0 && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo2 % 8 == 0 &&
+               a.ldaux % 8 == 0 && a.ldr % 4 == 0) {
+        static std::once_flag sk_attr;
+        std::call_once(sk_attr, [] {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_skinny_kernel<EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS_BYTES);
+        });
+        a.tiles_m = ce_div_up(a.M, 64);
+        a.tiles_n = ce_div_up(a.N, 64);
+        hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), SK_LDS_BYTES, stream, a);
     } else {
         hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), NT_LDS_BYTES, stream, a);
         if (EPI == CE_EPI_GELUGRAD_BF16 && a.out2) {   // the 128^2 kernel has no fused column sums

@@ -42,11 +42,11 @@ def test_gemm_nt_bf16_and_f32(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(400, 512, 256), (1100, 768, 512), (2000, 520, 256), (12800, 768, 768), (3000, 2048, 512),
-                                   (1300, 512, 192), (9000, 768, 256), (5000, 2304, 128), (20000, 3072, 64)])
+                                   (1300, 512, 192), (9000, 768, 256), (5000, 2304, 128), (20000, 3072, 64), (2000, 512, 64)])
 def test_gemm_nt_epilogues(M, N, K):
     """Every fused epilogue at shapes that reach each kernel family (128^2 register-staged; the single-round loader-wave
     kernel at its three tile heights: 96 rows (1100, 2000, 1300), 128 (9000), 160 (12800, 3000), ragged M / N edges, K of
-    1-3 tiles = shorter than its ring; the multi-round 256-column LDS-DMA kernels with the epilogue-operand prefetch)."""
+    1-3 tiles = shorter than its ring (2000 x 512 x 64: a single K tile); the multi-round 256-column LDS-DMA kernels with the epilogue-operand prefetch)."""
     from clip_event_amd import ops, _lib as L
     rng = np.random.default_rng(5 + M)
     a = _randn(rng, M, K).to(torch.bfloat16)
