@@ -11,6 +11,8 @@
 //   ce_cast_transpose    fp32 master weight -> bf16 copy + bf16 transposed copy
 //   ce_cast_bf16         fp32 -> bf16
 //   ce_eot_rows          argmax token id per row -> flat row index (model_clip.py:415)
+#include <limits.h>
+
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
@@ -239,20 +241,32 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict
     }
 }
 
-// rows[r] = r*Ltok + argmax_t ids[r, t]  (first maximum, like torch.argmax on these rows)
-__global__ void eot_rows_kernel(const long* __restrict__ ids, int* __restrict__ rows, long n, int Ltok) {
-    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+// rows[r] = r*Ltok + argmax_t ids[r, t]  (first maximum, like torch.argmax on these rows).  One wave per row, lane-strided
+// loads and a butterfly on (value, index): one memory latency per row (a thread per row walked 77 dependent loads:
+// 35 us at the head of the text path, ahead of the packing's host read-back).
+__global__ __launch_bounds__(256) void eot_rows_kernel(const long* __restrict__ ids, int* __restrict__ rows, long n, int Ltok) {
+    const int lane = threadIdx.x & 63;
+    const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= n) return;
-    long best = ids[r * Ltok];
-    int arg = 0;
-    for (int t = 1; t < Ltok; ++t) {
+    long best = LONG_MIN;
+    int arg = INT_MAX;
+    for (int t = lane; t < Ltok; t += 64) {
         const long v = ids[r * Ltok + t];
         if (v > best) {
             best = v;
             arg = t;
         }
     }
-    rows[r] = (int)(r * Ltok + arg);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long ob = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (ob > best || (ob == best && oa < arg)) {
+            best = ob;
+            arg = oa;
+        }
+    }
+    if (lane == 0) rows[r] = (int)(r * Ltok + arg);
 }
 
 // dst[dst_rows ? dst_rows[i] : i, :] = src[src_rows ? src_rows[i] : i, :]   (row_bytes multiple of 16)
@@ -379,7 +393,7 @@ extern "C" int ce_cast_bf16(const float* x, void* y, long n, void* stream) {
 
 extern "C" int ce_eot_rows(const int64_t* ids, int* rows, long n, int tokens, void* stream) {
     CE_CHECK_ARG(n > 0 && tokens > 0, "ce_eot_rows: bad shape");
-    hipLaunchKernelGGL(eot_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(eot_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const long*)ids, rows, n, tokens);
     CE_LAUNCH_CHECK();
     return 0;

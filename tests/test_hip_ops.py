@@ -461,3 +461,20 @@ def test_fused_infonce_against_pytorch(nq, nk, E, use_sel):
     assert _report("infonce dq", qd.grad.cpu(), q.grad)[1] < 2e-5
     assert _report("infonce dk", kd.grad.cpu(), k.grad)[1] < 2e-5
     assert abs(float(lsd.grad) - float(ls.grad)) < 2e-5 * max(1.0, abs(float(ls.grad)))
+
+
+@pytest.mark.parametrize("n,T", [(256, 77), (5, 200), (1, 1), (1000, 64)])
+def test_eot_rows_is_first_argmax(n, T):
+    """ce_eot_rows (the EOT position that model_clip.py:415 takes with text.argmax(dim=-1)): first maximum of every row,
+    rows with repeated maxima included; bit-exact against torch.argmax."""
+    import ctypes
+    from clip_event_amd import _lib as L
+    rng = np.random.default_rng(n + T)
+    ids = torch.from_numpy(rng.integers(0, 7, size=(n, T)).astype(np.int64))          # few distinct values: many ties
+    ids[::3, rng.integers(0, T)] = 49407
+    d = ids.to(DEV)
+    rows = torch.empty(n, dtype=torch.int32, device=DEV)
+    L.check(L.lib().ce_eot_rows(L.ptr(d), L.ptr(rows), ctypes.c_long(n), ctypes.c_int(T), L.stream()), "ce_eot_rows")
+    want = torch.arange(n) * T + ids.argmax(dim=-1)
+    assert torch.equal(rows.cpu().long(), want)
+
