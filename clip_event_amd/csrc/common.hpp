@@ -100,6 +100,12 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
     float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+// both at once (one sigmoid): g = QuickGELU(x), d = QuickGELU'(x)
+__device__ __forceinline__ void quick_gelu_both(float x, float& g, float& d) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    g = x * s;
+    d = s * (1.0f + 1.702f * x * (1.0f - s));
+}
 
 // ---- optional event profiler (runtime.cpp); a no-op unless ce_profile_enable(1) ----
 int ce_prof_begin(int cls, double flops, double bytes, hipStream_t s);

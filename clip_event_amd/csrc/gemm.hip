@@ -486,10 +486,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_nt256_kernel(NTArgs p) {
                     *reinterpret_cast<f32x4*>(o + 4) = v1;
                 } else if constexpr (PF_AUX) {
                     const u32x4 a = ap[mh * 8 + it];
-                    f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
-                                v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
-                    f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
-                                v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
+                    f32x4 r0 = {v0[0] * bf_lo(a[0]), v0[1] * bf_hi(a[0]), v0[2] * bf_lo(a[1]), v0[3] * bf_hi(a[1])};
+                    f32x4 r1 = {v1[0] * bf_lo(a[2]), v1[1] * bf_hi(a[2]), v1[2] * bf_lo(a[3]), v1[3] * bf_hi(a[3])};
                     cs0 += r0;
                     cs1 += r1;
                     u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};
@@ -969,10 +967,8 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
                     v1 += bias1;
                     if (PF_AUX && i * 2 + it < NPQ) {
                         const u32x4 a = ap[i * 2 + it < NPQ ? i * 2 + it : 0];
-                        f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
-                                    v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
-                        f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
-                                    v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
+                        f32x4 r0 = {v0[0] * bf_lo(a[0]), v0[1] * bf_hi(a[0]), v0[2] * bf_lo(a[1]), v0[3] * bf_hi(a[1])};
+                        f32x4 r1 = {v1[0] * bf_lo(a[2]), v1[1] * bf_hi(a[2]), v1[2] * bf_lo(a[3]), v1[3] * bf_hi(a[3])};
                         cs0 += r0;
                         cs1 += r1;
                         u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};

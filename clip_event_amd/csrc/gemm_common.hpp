@@ -44,16 +44,18 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& p, int m, int n, f32x4
         v += *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + n);
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = v;
     } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
-        // out = pre-activation a (bf16, kept for the backward), out2 = QuickGELU(a) (bf16)
-        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        // out = QuickGELU'(a) (bf16, kept for the backward), out2 = QuickGELU(a) (bf16), a = acc + bias
+        float gv[4], dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) quick_gelu_both(v[e], gv[e], dv[e]);
+        u32x2 o = {pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3])};
         *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
-        u32x2 g = {pack_bf2(quick_gelu_f(v[0]), quick_gelu_f(v[1])), pack_bf2(quick_gelu_f(v[2]), quick_gelu_f(v[3]))};
+        u32x2 g = {pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3])};
         *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = g;
     } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
-        // out = acc * QuickGELU'(a), a = saved bf16 pre-activation
+        // out = acc * aux, aux = the bf16 QuickGELU'(a) the forward epilogue saved
         u32x2 a = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
-        u32x2 o = {pack_bf2(v[0] * quick_gelu_grad_f(bf_lo(a[0])), v[1] * quick_gelu_grad_f(bf_hi(a[0]))),
-                   pack_bf2(v[2] * quick_gelu_grad_f(bf_lo(a[1])), v[3] * quick_gelu_grad_f(bf_hi(a[1])))};
+        u32x2 o = {pack_bf2(v[0] * bf_lo(a[0]), v[1] * bf_hi(a[0])), pack_bf2(v[2] * bf_lo(a[1]), v[3] * bf_hi(a[1]))};
         *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
     }
 }
@@ -97,18 +99,21 @@ __device__ __forceinline__ void nt_epilogue8(const NTArgs& p, int m, int n, f32x
         *reinterpret_cast<f32x4*>(o) = v0;
         *reinterpret_cast<f32x4*>(o + 4) = v1;
     } else if constexpr (EPI == CE_EPI_BIAS_GELU) {
-        u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
+        float gv[8], dv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            quick_gelu_both(v0[e], gv[e], dv[e]);
+            quick_gelu_both(v1[e], gv[4 + e], dv[4 + e]);
+        }
+        u32x4 o = {pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3]), pack_bf2(dv[4], dv[5]), pack_bf2(dv[6], dv[7])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;
-        u32x4 g = {pack_bf2(quick_gelu_f(v0[0]), quick_gelu_f(v0[1])), pack_bf2(quick_gelu_f(v0[2]), quick_gelu_f(v0[3])),
-                   pack_bf2(quick_gelu_f(v1[0]), quick_gelu_f(v1[1])), pack_bf2(quick_gelu_f(v1[2]), quick_gelu_f(v1[3]))};
+        u32x4 g = {pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3]), pack_bf2(gv[4], gv[5]), pack_bf2(gv[6], gv[7])};
         *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + n) = g;
     } else if constexpr (EPI == CE_EPI_GELUGRAD_BF16) {
         u32x4 a = *reinterpret_cast<const u32x4*>(p.aux + (long)m * p.ldaux + n);
-        f32x4 r0 = {v0[0] * quick_gelu_grad_f(bf_lo(a[0])), v0[1] * quick_gelu_grad_f(bf_hi(a[0])),
-                    v0[2] * quick_gelu_grad_f(bf_lo(a[1])), v0[3] * quick_gelu_grad_f(bf_hi(a[1]))};
-        f32x4 r1 = {v1[0] * quick_gelu_grad_f(bf_lo(a[2])), v1[1] * quick_gelu_grad_f(bf_hi(a[2])),
-                    v1[2] * quick_gelu_grad_f(bf_lo(a[3])), v1[3] * quick_gelu_grad_f(bf_hi(a[3]))};
-        cs0 += r0;      // column sums of the result = bias gradient of the Linear whose pre-activation this is
+        f32x4 r0 = {v0[0] * bf_lo(a[0]), v0[1] * bf_hi(a[0]), v0[2] * bf_lo(a[1]), v0[3] * bf_hi(a[1])};
+        f32x4 r1 = {v1[0] * bf_lo(a[2]), v1[1] * bf_hi(a[2]), v1[2] * bf_lo(a[3]), v1[3] * bf_hi(a[3])};
+        cs0 += r0;      // column sums of the result = bias gradient of the Linear whose activation derivative aux is
         cs1 += r1;
         u32x4 o = {pack_bf2(r0[0], r0[1]), pack_bf2(r0[2], r0[3]), pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])};
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.ldo + n) = o;

@@ -5,7 +5,7 @@
 //
 // Activation stash per block (rows M = batch*tokens, width d), all needed by the backward:
 //   x_in f32 (previous block's output), h1 bf16, qkv bf16 [M,3d], o bf16, lse f32,
-//   x_mid f32, h2 bf16, a bf16 [M,4d] (pre-GELU), g bf16 [M,4d], LayerNorm mean/rstd.
+//   x_mid f32, h2 bf16, a bf16 [M,4d] (QuickGELU' of the c_fc output), g bf16 [M,4d] (QuickGELU of it), LayerNorm mean/rstd.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -324,7 +324,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         const float* x_in = (l == 0) ? x0 : L.blk[l - 1].x_out;
         // ---- mlp.c_proj : x_out = x_mid + g Wp^T + bp ----
         TRY(linear(b8, L, dxb_a, w, p.wt_proj, p.wt8_proj, p.st8_proj, M, 4 * w, w, CE_EPI_GELUGRAD_BF16, nullptr, nullptr, 0, da, 4 * w, p.g_b_fc,
-                       4 * w, s.a, 4 * w, stream));                               // da = (dx Wp) * gelu'(a); g_b_fc += colsum(da)
+                       4 * w, s.a, 4 * w, stream));                               // da = (dx Wp) * a (the saved gelu'); g_b_fc += colsum(da)
         if (l == last) TRY(ce_colsum_bf16(dxb_a, w, p.g_b_proj, M, w, stream));   // lower blocks: fused in ln_1's backward
         // ---- mlp.c_fc : a = h2 Wf^T + bf ----
         TRY(linear(b8, L, da, 4 * w, p.wt_fc, p.wt8_fc, p.st8_fc, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,

@@ -56,9 +56,10 @@ enum {
     CE_EPI_BIAS_BF16 = 2,     /* out(bf16) = acc + bias[n]                                  */
     CE_EPI_BIAS_F32 = 3,      /* out(f32)  = acc + bias[n]                                  */
     CE_EPI_BIAS_RESID_F32 = 4,/* out(f32)  = resid(f32) + acc + bias[n]     (x + proj(..))  */
-    CE_EPI_BIAS_GELU = 5,     /* out(bf16) = a = acc + bias; out2(bf16) = a*sigmoid(1.702a) */
-    CE_EPI_GELUGRAD_BF16 = 6  /* out(bf16) = acc * dQuickGELU(aux(bf16)); out2 (nullable) is reused as a
-                               * float[N] that receives += the column sums of out (bias gradient)      */
+    CE_EPI_BIAS_GELU = 5,     /* a = acc + bias; out(bf16) = dQuickGELU(a) = s + 1.702 a s (1 - s), s = sigmoid(1.702 a): the
+                               * factor the backward needs, from the fp32 a; out2(bf16) = QuickGELU(a) = a s */
+    CE_EPI_GELUGRAD_BF16 = 6  /* out(bf16) = acc * aux(bf16), aux = the derivative BIAS_GELU saved; out2 (nullable) is reused as
+                               * a float[N] that receives += the column sums of out (bias gradient)      */
 };
 
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue.

@@ -62,15 +62,14 @@ def test_gemm_nt_epilogues(M, N, K):
     assert _report("bias_f32", o, acc + bias)[1] < 1e-5
     o = ops.gemm_nt(A, B, L.EPI_BIAS_RESID_F32, bias=bias.to(DEV), resid=resid.to(DEV)).cpu()
     assert _report("bias_resid", o, acc + bias + resid)[1] < 1e-5
-    pre, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+    dact, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
     h = acc + bias
-    assert _report("gelu pre", pre.float().cpu(), h)[1] < 3e-3
-    assert _report("gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
+    sg = torch.sigmoid(1.702 * h)
+    assert _report("gelu derivative", dact.float().cpu(), sg * (1 + 1.702 * h * (1 - sg)))[1] < 3e-3
+    assert _report("gelu act", g.float().cpu(), h * sg)[1] < 3e-3
     colsum = torch.zeros(N, device=DEV)
     o = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV), out2=colsum).float().cpu()
-    x = aux.float()
-    s = torch.sigmoid(1.702 * x)
-    want = acc * (s * (1 + 1.702 * x * (1 - s)))
+    want = acc * aux.float()                 # aux = the derivative the forward epilogue saved
     assert _report("gelugrad", o, want)[1] < 3e-3
     assert _report("gelugrad colsum", colsum.cpu(), want.sum(0))[1] < 3e-3
 
@@ -96,15 +95,14 @@ def test_gemm_nt_forced_tile_variants(variant):
         assert _report(f"v{variant} f32", o, acc)[1] < 1e-5
         o = ops.gemm_nt(A, B, L.EPI_BIAS_RESID_F32, bias=bias.to(DEV), resid=resid.to(DEV)).cpu()
         assert _report(f"v{variant} bias_resid", o, acc + bias + resid)[1] < 1e-5
-        pre, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+        dact, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
         h = acc + bias
-        assert _report(f"v{variant} gelu pre", pre.float().cpu(), h)[1] < 3e-3
-        assert _report(f"v{variant} gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
+        sg = torch.sigmoid(1.702 * h)
+        assert _report(f"v{variant} gelu derivative", dact.float().cpu(), sg * (1 + 1.702 * h * (1 - sg)))[1] < 3e-3
+        assert _report(f"v{variant} gelu act", g.float().cpu(), h * sg)[1] < 3e-3
         colsum = torch.zeros(N, device=DEV)
         o = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV), out2=colsum).float().cpu()
-        x = aux.float()
-        sg = torch.sigmoid(1.702 * x)
-        want = acc * (sg * (1 + 1.702 * x * (1 - sg)))
+        want = acc * aux.float()
         assert _report(f"v{variant} gelugrad", o, want)[1] < 3e-3
         assert _report(f"v{variant} colsum", colsum.cpu(), want.sum(0))[1] < 3e-3
     finally:
@@ -305,9 +303,7 @@ def test_gemm_nt_gelugrad_fused_colsum(M, N, K):
     check(lib().ce_gemm_nt(ptr(A), c_long(K), ptr(B), c_long(K), c_int(M), c_int(N), c_int(K), c_int(EPI_GELUGRAD_BF16), None,
                            None, c_long(0), ptr(out), c_long(N), ptr(cs), c_long(N), ptr(AUX), c_long(N), stream()), "gemm")
     torch.cuda.synchronize()
-    x = aux.float()
-    s = torch.sigmoid(1.702 * x)
-    ref = (a.float() @ b.float().t()) * (s * (1 + 1.702 * x * (1 - s)))
+    ref = (a.float() @ b.float().t()) * aux.float()          # aux = the QuickGELU' values the forward epilogue saved
     assert _report("gelugrad out", out.float().cpu(), ref)[1] < 3e-3
     assert _report("gelugrad colsum", cs.cpu(), ref.sum(0))[1] < 2e-3
 
@@ -415,15 +411,14 @@ def test_gemm_nt_fp8_epilogues():
     A8, SA, B8, SB = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV)
     o = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_BF16, bias=bias.to(DEV)).float().cpu()
     assert _report("fp8 bias_bf16", o, (acc + bias).to(torch.bfloat16).float())[1] < 3e-3
-    pre, g = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+    dact, g = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_GELU, bias=bias.to(DEV))
     h = acc + bias
-    assert _report("fp8 gelu pre", pre.float().cpu(), h)[1] < 3e-3
-    assert _report("fp8 gelu act", g.float().cpu(), h * torch.sigmoid(1.702 * h))[1] < 3e-3
+    sg = torch.sigmoid(1.702 * h)
+    assert _report("fp8 gelu derivative", dact.float().cpu(), sg * (1 + 1.702 * h * (1 - sg)))[1] < 3e-3
+    assert _report("fp8 gelu act", g.float().cpu(), h * sg)[1] < 3e-3
     colsum = torch.zeros(N, device=DEV)
     o = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_GELUGRAD_BF16, aux=aux.to(DEV), colsum=colsum).float().cpu()
-    x = aux.float()
-    s = torch.sigmoid(1.702 * x)
-    want = acc * (s * (1 + 1.702 * x * (1 - s)))
+    want = acc * aux.float()
     assert _report("fp8 gelugrad", o, want)[1] < 3e-3
     assert _report("fp8 gelugrad colsum", colsum.cpu(), want.sum(0))[1] < 2e-3
 

@@ -48,16 +48,27 @@ def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
 
 def sample_agreement(t: torch.Tensor, gold: dict):
     """Direction check on the 32 sampled values a golden summary stores (``idx`` / ``val``, make_golden.py:70-75):
-    returns ``(cosine of the sampled vectors, max |difference| / scale)`` with scale = the larger of the golden tensor's
-    RMS and the RMS of its sampled values (a sparse gradient such as the token embedding's has samples far above the
-    tensor RMS).  A gradient with the
-    right norm but the wrong sign, layout or transposition fails this although its norm matches.  ``(None, 0.0)``
-    when the golden samples are all (near) zero."""
+    returns ``(cosine of the sampled vectors, max |difference|)`` with every sample expressed in units of a LOCAL scale:
+    the RMS of the row (last dimension) of ``t`` it sits in, floored at 1 % of the golden tensor's RMS, and for 1-D
+    tensors the larger of the golden tensor's RMS and the RMS of its sampled values.  Gradients of embedding-like
+    tensors have per-row scales -- ``visual.positional_embedding``'s CLS row carries 7x the tensor RMS, every other row
+    0.04x -- and rounding noise follows the local scale: one small entry of the big row would otherwise decide the
+    cosine (the oracle's own bf16 mode against its fp32 mode: 0.887 un-scaled).  A gradient with the right norm but the
+    wrong sign, layout or transposition fails this although its norm matches.  ``(None, err)`` when the golden samples
+    are all (near) zero."""
     _, _, vals = summary_of(t, gold["idx"])
     ref = np.asarray(gold["val"], dtype=np.float64)
     rms = gold["norm"] / max(t.numel(), 1) ** 0.5
     nr = float(np.linalg.norm(ref))
-    err = float(np.abs(vals - ref).max() / max(rms, nr / len(ref) ** 0.5, 1e-30))
+    if t.dim() >= 2 and t.shape[-1] >= 16:
+        rows = t.detach().double().reshape(-1, t.shape[-1])
+        row_rms = rows.pow(2).mean(dim=1).sqrt().cpu().numpy()
+        scale = np.maximum(row_rms[np.asarray(gold["idx"]) // t.shape[-1]], 1e-2 * rms)
+    else:
+        scale = np.full(len(ref), max(rms, nr / len(ref) ** 0.5))
+    scale = np.maximum(scale, 1e-30)
+    err = float((np.abs(vals - ref) / scale).max())
     if nr <= 1e-3 * rms * len(ref) ** 0.5:
         return None, err
-    return float(vals @ ref / (np.linalg.norm(vals) * nr + 1e-300)), err
+    a, b = vals / scale, ref / scale
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300)), err
