@@ -850,8 +850,8 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
         const uint32_t vB0 = (uint32_t)((lw * 8 + s_row) * p.ldb * 2 + s_chunk * 16);
         const uint32_t stepA = (uint32_t)(8 * N4_LOADERS * p.lda * 2), stepB = (uint32_t)(8 * N4_LOADERS * p.ldb * 2);
         auto desc = [&](int t, u32x4& rA, u32x4& rB) {
-            const int tile = xb + t * G;
-            const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+            int tm, tn;
+            strip_tile_coords(p, xb + t * G, tm, tn);
             const int m0 = tm * BM, n0 = tn * N4_BN;
             rA = make_rsrc_words(p.A + (long)m0 * p.lda, (uint32_t)((long)min(p.M - m0, BM) * p.lda * 2));
             rB = make_rsrc_words(p.B + (long)n0 * p.ldb, (uint32_t)((long)min(p.N - n0, N4_BN) * p.ldb * 2));
@@ -897,8 +897,8 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
     const int e_r = lane >> 3, e_c = (lane & 7) * 8;
     int slot = 0;
     for (int t = 0; t < n_my; ++t) {
-        const int tile = xb + t * G;
-        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+        int tm, tn;
+        strip_tile_coords(p, xb + t * G, tm, tn);
         const int m0 = tm * BM, n0 = tn * N4_BN;
         f32x4 acc[TM][4];
 #pragma unroll
@@ -1842,19 +1842,19 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         // against the 160x128 pair below, which was itself 0.5-2 % ahead of the plain 8-wave tile because a workgroup of
         // the OTHER tower's GEMM could share the CU).  CE_NT_POLICY: bit 0 = treat single-round launches specially
         // (default), bit 4 = with the loader-wave kernel (default; without it the 160x128 four-wave pair), bits 5, 6 = the
-        // persistent loader-wave kernel for multi-round launches (below; off), bit 1 = also
+        // persistent loader-wave kernel for multi-round launches (below; default), bit 1 = also
         // instead of the two-workgroup 160x256x32 kernel (slower), bit 2 = pick the 160x128 family's tile height 96..160 by
         // rounds over the 512 slots (slower in the step), bit 3 = also for multi-round launches (noise).
-        static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 17;
+        static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 113;
         const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
         const bool half = f == 104 || (f >= 203 && f <= 205) ||
                           (f == 0 && (half_tiles <= 512 || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
         const bool lw = f == 161 || (half && f == 0 && (policy & 16));       // one 160x256 loader-wave workgroup per CU
         prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + (lw ? 5 : (half || f == 104 ? 1 : (use32 ? 3 : 2))));
-        // multi-round launches: the persistent loader-wave kernel, OFF by default.  Bit 5 = for the light epilogues (qkv
-        // forward: 726 -> 812 TF/s as a kernel, but the step does not move: 14.04 / 14.28 ms without, 14.41 / 14.22 with --
-        // a grid that holds every CU for its whole run leaves the other tower's stream nothing to overlap); bit 6 = also
-        // for the GELU epilogues, where it loses to the two-workgroup 160x256x32 kernel even as a kernel (509 vs 560 TF/s)
+        // multi-round launches: the persistent loader-wave kernel.  Bit 5 = for the light epilogues (qkv forward: 726 ->
+        // 810 TF/s), bit 6 = also for the GELU epilogues (as kernels about equal to the two-workgroup 160x256x32 kernel
+        // since their epilogues lost the division and the backward's transcendentals).  Both on by default: B = 256 step
+        // 14.15 -> 14.00 (bit 5) -> 13.96 ms (bits 5 + 6), config 4 at B = 64 32.3 -> 31.9 -> 31.5 ms.
         constexpr bool light_epi = EPI == CE_EPI_BF16 || EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_F32;
         const bool pers = !lw && a.K >= 2 * N4_BK && ((f >= 163 && f <= 165) || f == 162 ||
                                                      (f == 0 && !half && ((policy & 32) && light_epi || (policy & 64))));
@@ -1871,6 +1871,8 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                 }
             }
             a.tiles_m = ce_div_up(a.M, 32 * ptm);
+            static const int strip = getenv("CE_NT_STRIP") ? atoi(getenv("CE_NT_STRIP")) : 0;   // column strips: measured no better (0 / 3 / 6 equal, 4 slower)
+            a.tile_strip = strip;
             const long tiles = (long)a.tiles_m * a.tiles_n;
             const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(64 * (8 + N4_LOADERS));
             prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 5);

@@ -14,6 +14,7 @@ struct NTArgs {
     bf16_t* out2; long ldo2;
     const bf16_t* aux; long ldaux;
     int tiles_m, tiles_n;
+    int tile_strip = 0;          // persistent kernel: tiles are walked in column strips of this many tiles (0: row-major)
     const float* sa = nullptr;   // fp8 path: per-row dequantisation scales of A (M) ...
     const float* sb = nullptr;   // ... and of B (N); the epilogue multiplies the accumulator by sa[m] * sb[n]
 };
@@ -26,6 +27,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7;
     int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + local;
+}
+
+// tile index -> (tm, tn) in column strips of p.tile_strip tile columns, row-major inside a strip: the 32 consecutive
+// tiles an XCD holds in one round of the persistent kernel are then 8 row panels x 4 column panels (12 A/B panels through
+// its L2) instead of 2.7 x 12 (15 panels, the 12 of B re-read every round).  Measured: no gain in the step (CE_NT_STRIP, off).
+__device__ __forceinline__ void strip_tile_coords(const NTArgs& p, int tile, int& tm, int& tn) {
+    const int gw = p.tile_strip;
+    if (gw <= 0 || gw >= p.tiles_n) {
+        tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+        return;
+    }
+    const int per = gw * p.tiles_m;
+    const int strip = tile / per;
+    const int within = tile - strip * per;
+    const int w = min(gw, p.tiles_n - strip * gw);      // the last strip may be narrower
+    tm = within / w;
+    tn = strip * gw + within - tm * w;
 }
 
 // fused epilogue for one lane's 4 consecutive output columns n..n+3 of row m
