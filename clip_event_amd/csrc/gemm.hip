@@ -1875,7 +1875,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             a.tile_strip = strip;
             const long tiles = (long)a.tiles_m * a.tiles_n;
             const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(64 * (8 + N4_LOADERS));
-            prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 5);
+            prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 6);
             switch (ptm) {
                 case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3>), grid, block, N4_LDS_BYTES, stream, a); break;
                 case 4: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4>), grid, block, N4_LDS_BYTES, stream, a); break;

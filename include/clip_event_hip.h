@@ -34,15 +34,15 @@ int ce_version(void);
 /* ---- optional profiler: HIP events on the launch stream around every launch, summed per kernel
  * class.  ce_profile_collect fills out[class][4] = {launches, total ms, algorithmic FLOPs, algorithmic
  * bytes} and resets.  Used by bench.py for the `roofline` object; off by default. ---- */
-#define CE_PROF_NT_FAMILIES 6
+#define CE_PROF_NT_FAMILIES 7
 enum {
     CE_PROF_GEMM_NT0 = 0, /* + CE_PROF_NT_FAMILIES * epilogue id (0..6) + kernel family: 0 gemm_nt_kernel (128x128, register
                            * staged), 1 gemm_nt256_kernel<.,.,2> (160x128, 4 waves), 2 gemm_nt256_kernel<.,.,4> (256 columns,
                            * 8 waves), 3 gemm_nt32_kernel (160x256x32), 4 gemm_nt8_kernel (fp8), 5 gemm_nt160lw_kernel (160x256,
-                           * loader waves) -- one class per rocprofv3 kernel row */
-    CE_PROF_GEMM_TN = 42, CE_PROF_ATTN_FWD = 43, CE_PROF_ATTN_BWD = 44, CE_PROF_LN_FWD = 45, CE_PROF_LN_BWD = 46,
-    CE_PROF_COLSUM = 47, CE_PROF_OTHER = 48, CE_PROF_GEMM_TN2 = 49 /* gemm_tn2_kernel; CE_PROF_GEMM_TN = gemm_tn3_kernel */,
-    CE_PROF_NCLASS = 50
+                           * loader waves), 6 gemm_nt160p_kernel (its persistent form) -- one class per rocprofv3 kernel row */
+    CE_PROF_GEMM_TN = 49, CE_PROF_ATTN_FWD = 50, CE_PROF_ATTN_BWD = 51, CE_PROF_LN_FWD = 52, CE_PROF_LN_BWD = 53,
+    CE_PROF_COLSUM = 54, CE_PROF_OTHER = 55, CE_PROF_GEMM_TN2 = 56 /* gemm_tn2_kernel; CE_PROF_GEMM_TN = gemm_tn3_kernel */,
+    CE_PROF_NCLASS = 57
 };
 void ce_profile_enable(int on);
 int ce_profile_collect(double* out, int max_classes);
