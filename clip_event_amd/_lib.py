@@ -23,6 +23,12 @@ class HipExtensionMissing(RuntimeError):
     pass
 
 
+class QuantJob(ctypes.Structure):
+    """``ce_quant_job`` of include/clip_event_hip.h."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("scale", c_void_p), ("lds_", ctypes.c_long), ("ldd", ctypes.c_long),
+                ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("group_start", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
 class TransposeJob(ctypes.Structure):
     """``ce_transpose_job`` of include/clip_event_hip.h."""
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),

@@ -224,6 +224,48 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restric
     }
 }
 
+// the same, for a table of matrices (block-uniform linear search of the job, as multi_transpose_kernel)
+__global__ __launch_bounds__(256) void quant_rows_multi_kernel(const ce_quant_job* __restrict__ jobs, int njobs) {
+    int j = 0;
+    const int bidx = blockIdx.x;
+    while (j + 1 < njobs && bidx >= jobs[j + 1].group_start) ++j;
+    const ce_quant_job job = jobs[j];
+    const int row = (bidx - job.group_start) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= job.rows) return;
+    const int chunks = job.cols >> 3;
+    const bf16_t* xr = reinterpret_cast<const bf16_t*>(job.src) + (long)row * job.lds_;
+    u32x4 v[8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (c < chunks) v[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(v[i][e])), fabsf(bf_hi(v[i][e]))));
+    }
+    amax = wave_max(amax);
+    const uint32_t ab = __float_as_uint(amax);
+    const bool live = amax >= 7.8886090522101181e-31f;
+    const int e = 9 - ((int)((ab >> 23) & 0xff) - 126) - (((ab & 0x7fffffu) > 0x600000u) ? 1 : 0);
+    const float inv = live ? __uint_as_float((uint32_t)(e + 127) << 23) : 1.0f;
+    if (lane == 0) job.scale[row] = live ? __uint_as_float((uint32_t)(127 - e) << 23) : 1.0f;
+    uint8_t* qr = reinterpret_cast<uint8_t*>(job.dst) + (long)row * job.ldd;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= chunks) continue;
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][0]) * inv, bf_hi(v[i][0]) * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][1]) * inv, bf_hi(v[i][1]) * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][2]) * inv, bf_hi(v[i][2]) * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[i][3]) * inv, bf_hi(v[i][3]) * inv, w1, true);
+        u32x2 o = {(uint32_t)w0, (uint32_t)w1};
+        *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+    }
+}
+
 template <int EPI, int TM, int WN>
 void launch8(NTArgs& a, hipStream_t stream) {
     static std::once_flag attr;
@@ -286,6 +328,13 @@ extern "C" int ce_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, flo
     else if (cpl <= 2) hipLaunchKernelGGL(quant_rows_kernel<2>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
     else if (cpl <= 4) hipLaunchKernelGGL(quant_rows_kernel<4>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
     else hipLaunchKernelGGL(quant_rows_kernel<8>, grid, block, 0, s, xs, ldx, qs, ldq, scale, M, K);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_quant_rows_fp8_multi(const ce_quant_job* jobs_device, int njobs, int total_groups, void* stream) {
+    CE_CHECK_ARG(jobs_device && njobs > 0 && total_groups > 0, "ce_quant_rows_fp8_multi: empty");
+    hipLaunchKernelGGL(quant_rows_multi_kernel, dim3(total_groups), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
     CE_LAUNCH_CHECK();
     return 0;
 }

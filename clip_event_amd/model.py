@@ -499,19 +499,33 @@ class CLIP(nn.Module):
                     setattr(f, "wt8_" + short, t[2].data_ptr())
                     setattr(f, "st8_" + short, t[3].data_ptr())
         self._fp8_fresh = False
+        self._qjobs_key = None
 
     def _refresh_fp8(self):
         """Requantise from the bf16 operand copies (they have just been refreshed from the masters)."""
         if self._w8 is None:
             self._build_fp8_tables()
         cl, s = lib(), stream()
-        for n, (w8, s8, w8t, s8t) in self._w8.items():
-            o, k = w8.shape
-            check(cl.ce_quant_rows_fp8(ptr(self._w16[n]), c_long(k), ptr(w8), c_long(k), ptr(s8), c_int(o), c_int(k), s),
-                  "ce_quant_rows_fp8(w)")
-            if self.fp8 & 2:
-                check(cl.ce_quant_rows_fp8(ptr(self._w16t[n]), c_long(o), ptr(w8t), c_long(o), ptr(s8t), c_int(k), c_int(o), s),
-                      "ce_quant_rows_fp8(wt)")
+        key = int(self.fp8) & 2
+        if getattr(self, "_qjobs_key", None) != key:
+            # one launch for every weight (and, with the input-gradient GEMMs in fp8, every transposed copy): a job table in
+            # device memory, as for the transposes
+            from ._lib import QuantJob
+            jobs, groups = [], 0
+            for n, (w8, s8, w8t, s8t) in self._w8.items():
+                o, k = w8.shape
+                todo = [(self._w16[n], w8, s8, o, k)] + ([(self._w16t[n], w8t, s8t, k, o)] if key else [])
+                for src, dst, sc, rows, cols in todo:
+                    if cols > 4096:
+                        raise RuntimeError("fp8 weight rows longer than 4096 are not supported")
+                    jobs.append(QuantJob(src.data_ptr(), dst.data_ptr(), sc.data_ptr(), cols, cols, rows, cols, groups, 0))
+                    groups += (rows + 3) // 4
+            arr = (QuantJob * len(jobs))(*jobs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._qjobs = host.to(self._flat.device)
+            self._qjobs_n, self._qjobs_groups, self._qjobs_key = len(jobs), groups, key
+        check(cl.ce_quant_rows_fp8_multi(ptr(self._qjobs), c_int(self._qjobs_n), c_int(self._qjobs_groups), s),
+              "ce_quant_rows_fp8_multi")
         self._fp8_fresh = True
 
     def refresh_operands(self, force: bool = False):

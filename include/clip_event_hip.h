@@ -91,6 +91,16 @@ int ce_gemm_tn_grouped(int count, const void* const* P, const long* ldp, const v
  * q[r,:] (e4m3 bytes) = x[r,:] (bf16) * 2^e_r with the power of two that puts the row's amax into (224, 448],
  * scale[r] = 2^-e_r (1 for an all-zero row); exact scaling, so the bytes are reproducible anywhere; K <= 4096 */
 int ce_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, void* stream);
+/* the same quantisation for a table of matrices in ONE launch (the per-step requantisation of every block weight and
+ * its transpose: 288 launches of a few microseconds each otherwise).  jobs live in device memory; tile_start = first
+ * 4-row group of the job in the launch's grid; K <= 4096. */
+typedef struct ce_quant_job {
+    const void* src; void* dst; float* scale;
+    long lds_; long ldd;         /* leading dimensions: src in bf16 elements, dst in bytes */
+    int rows, cols;
+    int group_start, pad_;
+} ce_quant_job;
+int ce_quant_rows_fp8_multi(const ce_quant_job* jobs_device, int njobs, int total_groups, void* stream);
 /* C[m,n] = sa[m] * sb[n] * sum_k A8[m,k] * B8[n,k] (e4m3 operands, one fp32 scale per row of each, fp32 accumulate on
  * v_mfma_scale_f32_16x16x128_f8f6f4) with the fused epilogues of ce_gemm_nt (BF16, BIAS_BF16, BIAS_RESID_F32, BIAS_GELU,
  * GELUGRAD_BF16).  K % 128 == 0; lda/ldb in bytes (= elements). */

@@ -473,3 +473,26 @@ def test_eot_rows_is_first_argmax(n, T):
     want = torch.arange(n) * T + ids.argmax(dim=-1)
     assert torch.equal(rows.cpu().long(), want)
 
+
+def test_quant_rows_fp8_multi_equals_single_launches():
+    """ce_quant_rows_fp8_multi (one launch for a table of matrices: the per-step weight requantisation) writes the same
+    bytes and scales as one ce_quant_rows_fp8 launch per matrix; row counts not multiples of 4, K from 64 to 4096."""
+    import ctypes
+    from clip_event_amd import ops, _lib as L
+    rng = np.random.default_rng(7)
+    shapes = [(768, 768), (13, 64), (3072, 1024), (1024, 4096), (5, 512)]
+    mats = [(_randn(rng, m, k) * (10.0 ** rng.uniform(-3, 2))).to(torch.bfloat16).to(DEV) for m, k in shapes]
+    want = [ops.quant_rows_fp8(x) for x in mats]
+    outs = [(torch.zeros(m, k, dtype=torch.uint8, device=DEV), torch.zeros(m, dtype=torch.float32, device=DEV)) for m, k in shapes]
+    jobs, groups = [], 0
+    for x, (q, sc), (m, k) in zip(mats, outs, shapes):
+        jobs.append(L.QuantJob(x.data_ptr(), q.data_ptr(), sc.data_ptr(), k, k, m, k, groups, 0))
+        groups += (m + 3) // 4
+    arr = (L.QuantJob * len(jobs))(*jobs)
+    dev_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    L.check(L.lib().ce_quant_rows_fp8_multi(L.ptr(dev_jobs), ctypes.c_int(len(jobs)), ctypes.c_int(groups), L.stream()),
+            "ce_quant_rows_fp8_multi")
+    torch.cuda.synchronize()
+    for (q, sc), (wq, wsc) in zip(outs, want):
+        assert torch.equal(q, wq) and torch.equal(sc, wsc)
+
