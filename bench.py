@@ -27,8 +27,14 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_PAIR = 44.10e9        # ViT-B/32 fwd+bwd, K=1, no patch-conv dgrad
-TEXT_FLOP_PER_PAIR = 3 * 2 * 2.9798e9   # text tower's share of it (2.9798 GMAC/caption fwd)
+# per geometry: default per-GPU batch, nominal fwd+bwd FLOP per pair at K = 1 (BASELINE.md section 3 / SURVEY 8(d): ViT-B/32
+# 44.10 G without the never-needed patch-conv dgrad; ViT-L/14@336 1185.7 G), the text tower's share of it per caption
+# (ViT-B/32: 3 * 2 * 2.9798 GMAC; ViT-L/14: (1345.3 - 1185.7) / 4), name for the workload string
+ARCH = {
+    "vit_b32": (256, 44.10e9, 3 * 2 * 2.9798e9, "ViT-B/32 224px"),
+    "vit_b16": (128, 3 * 2 * (17.58e9 + 2.9798e9), 3 * 2 * 2.9798e9, "ViT-B/16 224px"),
+    "vit_l14_336": (32, 1185.7e9, (1345.3e9 - 1185.7e9) / 4, "ViT-L/14 336px"),
+}
 PEAK_BF16 = 2.5e15             # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 
@@ -38,7 +44,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU image batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU image batch (default: 256 for ViT-B/32, 32 for ViT-L/14@336)")
+    ap.add_argument("--arch", default="vit_b32", choices=sorted(ARCH),
+                    help="geometry: vit_b32 = the headline metric (BASELINE configs 1-4); vit_l14_336 = BASELINE config 5")
+    ap.add_argument("--fp8", type=int, nargs="?", const=3, default=0,
+                    help="BASELINE config 5's fp8 MFMA weight path: bit 0 forward GEMMs, bit 1 input-gradient GEMMs (bare --fp8 = 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--descriptions", type=int, default=1,
@@ -52,6 +62,9 @@ def parse():
                     help="hand the model the SAME caption tensor every step (its live-token layout is then cached; the "
                          "default gives every step a new tensor, so the per-batch length read-back of real training is "
                          "inside the timed region)")
+    ap.add_argument("--device-lengths", action="store_true",
+                    help="do not hand the captions' host-side lengths to the step: the text tower then reads the EOT "
+                         "positions back from the device once per new caption tensor (a synchronous 1 KB copy)")
     ap.add_argument("--alignment", action="store_true",
                     help="BASELINE config 4: add sim_entity + the IPOT alignment loss (object crops / entity mentions "
                          "as SURVEY 8(d) c4: 1+U[0,6] objects, U[1,10] entities per image)")
@@ -180,8 +193,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one command starts the ranks (the reference's launch contract: train.sh:2, utils.py:541-616): N fresh child
         # interpreters, one per GPU, BEFORE this process makes any device call; rank 0's JSON line is relayed.
-        from clip_event_amd.launch import spawn_ranks
-        visible = torch.cuda.device_count()          # counting devices does not initialise HIP in this process
+        from clip_event_amd.launch import spawn_ranks, visible_gpus
+        visible = visible_gpus()                     # visibility variables / KFD sysfs: no HIP call in the parent
         if visible and visible < args.gpus and not os.environ.get("CE_ALL_RANKS_ON_GPU0"):
             log(f"--gpus {args.gpus} but only {visible} GPU(s) visible (CE_ALL_RANKS_ON_GPU0=1 rehearses the ranks on one GPU over gloo)")
             sys.exit(2)
@@ -224,21 +237,25 @@ def main():
     from clip_event_amd.model import build_model
     from clip_event_amd.optim import FusedAdam
 
-    B = args.batch
-    model = S.synthetic_model("vit_b32", seed=0).to(dev)         # same weights on every rank
+    B_default, FLOP_PER_PAIR, TEXT_FLOP_PER_PAIR, arch_name = ARCH[args.arch]
+    B = args.batch or B_default
+    model = S.synthetic_model(args.arch, seed=0).to(dev)         # same weights on every rank
+    model.fp8 = int(args.fp8)
+    R = model.visual.input_resolution
     model.tower_streams = not args.single_stream
     crit = CriterionContrastive("ce")
     opt = FusedAdam(model, lr=1e-6, weight_decay=0.0, max_norm=1.0)    # README.md:189-191 defaults
     sync = D.GradSync(model) if ((W > 1 or force) and os.environ.get("CE_NO_GRAD_SYNC", "0") != "1") else None
-    img = S.synthetic_images(B, 224, seed=999 + rank).to(dev)
+    img = S.synthetic_images(B, R, seed=999 + rank).to(dev)
     K = max(1, args.descriptions)
-    txt = S.synthetic_tokens(B * K, 77, 49408, seed=999 + rank).to(dev)
+    txt_host = S.synthetic_tokens(B * K, 77, 49408, seed=999 + rank)
+    txt = txt_host.to(dev)
     yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=dev, rank_=rank)
     extra = {}
     if args.alignment:
         from clip_event_amd.losses import CriterionAlignment
         model.set_hyps(True, True, False)
-        obj, obj_num, ent, ent_num = S.synthetic_entities(B, 224, 77, 49408, seed=1999 + rank)
+        obj, obj_num, ent, ent_num = S.synthetic_entities(B, R, 77, 49408, seed=1999 + rank)
         extra.update(criterion_ot=CriterionAlignment(), object_vec=obj.to(dev), entitytxt_vec=ent.to(dev),
                      object_num=obj_num.to(dev), entitytxt_num=ent_num.to(dev))
         log(f"alignment: object_vec {tuple(obj.shape)}, entitytxt_vec {tuple(ent.shape)}")
@@ -248,11 +265,37 @@ def main():
                      bbox_desc_vec=[t.to(dev) for t in S.synthetic_role_texts(boxes, seed=3999 + rank)],
                      bbox_label_vec=[t.to(dev) for t in S.synthetic_role_texts(boxes, seed=4999 + rank)])
 
+    # what one step pushes through the towers: images / captions of the main batch plus, in config 4, the object crops and
+    # entity mentions of sim_entity (engine.py:57-63; padding slots are encoded too, as in the reference) and the role
+    # descriptions (+ labels) of the usable boxes of the region branch (model_clip.py:430-488)
+    n_img, n_txt = B, B * K
+    txt_live = int((txt_host.argmax(dim=-1) + 1).sum())
+    if args.alignment:
+        n_img += obj.shape[0] * obj.shape[1]
+        n_txt += ent.shape[0] * ent.shape[1]
+        txt_live += int((ent.reshape(-1, ent.shape[-1]).argmax(dim=-1) + 1).sum())
+    if args.train_arg:
+        reps = 2 if args.train_arg.startswith("desc_type") else 1
+        for bx, rows_ in zip(boxes, extra["bbox_desc_vec"]):
+            if not bx or bx[-1] is None:                      # model_clip.py:450-455: the image contributes nothing
+                continue
+            use = [i for i, b_ in enumerate(bx) if b_ is not None]
+            n_txt += reps * len(use)
+            txt_live += reps * int((rows_[use].argmax(dim=-1) + 1).sum())
+
     if args.dense_text:
         model.pack_text = False
 
+    # the data loader's side of the contract: every step gets a NEW caption tensor in HBM (fresh storage, as a real batch
+    # would be) together with the captions' lengths, which the tokenizer knows on the host (clip.tokenize / attach_lengths);
+    # --device-lengths withholds them, so the text tower reads the EOT positions back from the device each step
+    from clip_event_amd.functional import attach_lengths, host_lengths
+    txt_lens = None if args.device_lengths else host_lengths(txt_host)
+
     def step():
         t = txt if args.reuse_captions else txt.clone()
+        if txt_lens is not None:
+            attach_lengths(t, txt_lens)
         return train_step(model, crit, opt, img, t, yi, yt, ip, grad_sync=sync, **extra)
 
     def timed(nsteps):
@@ -280,10 +323,9 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = B * W * args.steps / dt
     # text rows the tower actually ran on (live tokens SOT..EOT) vs the dense [B, 77] layout
-    lens = (txt.argmax(dim=-1) + 1).sum().item()
-    live_frac = 1.0 if args.dense_text else lens / float(B * K * 77)
+    live_frac = 1.0 if args.dense_text else txt_live / float(n_txt * 77)
     dense = None
-    if not args.dense_text and not args.no_dense_compare and not extra:      # the same step with every caption padded out to 77 rows, for comparison
+    if not args.dense_text and not args.no_dense_compare and not extra and args.arch == "vit_b32":      # the same step with every caption padded out to 77 rows, for comparison
         model.pack_text = False
         nd = max(5, args.steps // 2)
         for _ in range(2):
@@ -325,6 +367,7 @@ def main():
                              "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                              "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
         rows.sort(key=lambda r: -r["ms_per_step"])
+        issued_flops = sum(r["tflops"] * 1e12 * r["ms_per_step"] * 1e-3 for r in rows)
     if rank == 0 and not args.no_roofline and rows:
         top = rows[0]
         mfma = top["kernel"].startswith("gemm") or top["kernel"].startswith("attn")
@@ -336,15 +379,21 @@ def main():
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(top["gbps"] * 1e9 * top["avg_us"] * 1e-6),
                 "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
-                # step_frac = the FLOPs the step actually ISSUES (text-tower GEMM work scales with the live-row
-                # fraction of the packed layout) / time / peak: the figure to hold against the 40 % target.  The
-                # nominal figure prices every pair at SURVEY 8(d)'s 44.10 GFLOP (all 77 text positions) and is
-                # kept only for comparison with dense-text implementations.
-                "step_frac": round(
-                    pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR
-                                       - K * TEXT_FLOP_PER_PAIR * (1.0 - live_frac)) / PEAK_BF16, 4),
-                "step_frac_nominal_44_10_gflop_per_pair": round(
-                    pairs_per_s / W * (FLOP_PER_PAIR + (K - 1) * TEXT_FLOP_PER_PAIR) / PEAK_BF16, 4),
+                # step_frac = the FLOPs the kernels of one step ISSUE (sum over the instrumented pass's classes: packed text
+                # rows, the pruned last block of each tower and the loss head as they really run) / the timed step / peak:
+                # the hardware utilisation, and the figure to hold against the 40 % target.  The two figures after it price the
+                # step by the analytic model instead: every image at the image tower's and every caption at the text tower's
+                # share of SURVEY 8(d)'s FLOP per pair -- with the text share scaled by the live-row fraction ("model"), and
+                # with all 77 positions ("nominal": comparable with dense-text implementations, overstates what ran).
+                "step_frac": round(issued_flops / (ms_per_step * 1e-3) / PEAK_BF16, 4),
+                "issued_tflop_per_step": round(issued_flops / 1e12, 4),
+                "step_frac_model_live_text_rows": round(
+                    (n_img * (FLOP_PER_PAIR - TEXT_FLOP_PER_PAIR) + n_txt * TEXT_FLOP_PER_PAIR * live_frac)
+                    / (ms_per_step * 1e-3) / PEAK_BF16, 4),
+                "step_frac_nominal": round(
+                    (n_img * (FLOP_PER_PAIR - TEXT_FLOP_PER_PAIR) + n_txt * TEXT_FLOP_PER_PAIR) / (ms_per_step * 1e-3) / PEAK_BF16, 4),
+                "nominal_gflop_per_pair": round(FLOP_PER_PAIR / 1e9, 2),
+                "tower_rows_per_step": {"images": n_img, "captions": n_txt, "live_text_row_fraction": round(live_frac, 4)},
                 "mfma_utilisation": mfma_util(),
                 "classes": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
     if W > 1:
@@ -356,13 +405,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "image-text pairs/sec/GPU, ViT-B/32 224px x 77-tok, global-batch contrastive",
+            "metric": "image-text pairs/sec/GPU, %s x 77-tok, global-batch contrastive" % arch_name,
             "value": round(pairs_per_s, 2), "unit": "pairs/s (whole job)", "per_gpu": round(pairs_per_s / W, 2),
             "n_gpus": W, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-B/32 224px x 77-tok, per-GPU batch %d, K=%d, %s, full train step "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": "%s x 77-tok, %s, per-GPU batch %d, K=%d, %s, full train step "
                                    "(fwd+bwd+clip_grad_norm+Adam), random-init weights"
-                                   % (B, K, "InfoNCE only" if not extra else "InfoNCE" + (" + OT alignment" if args.alignment else "")
+                                   % (arch_name, ("fp8 (e4m3) weight path, bits %d" % args.fp8) if args.fp8 else "bf16 operands", B, K,
+                                      "InfoNCE only" if not extra else "InfoNCE" + (" + OT alignment" if args.alignment else "")
                                       + (" + region branch (%s)" % args.train_arg if args.train_arg else "")),
                        "global_batch": B * W, "parallelism": "dp%d" % W, "loss": round(loss, 4),
                        "captions": "SOT + U[8,75] random ids + EOT, zero-padded to 77 (SURVEY 8(d) c2)",

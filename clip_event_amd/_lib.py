@@ -62,3 +62,18 @@ def ptr(t) -> c_void_p:
 
 def stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_SAT = {}
+
+
+def sat_counters(device) -> torch.Tensor:
+    """The process-wide device buffer of the fp16-stream saturation counters (``ce_stream16_set_counters``): int32
+    [forward stream, gradient stream].  One process drives one GPU, so one buffer, registered once and never freed (the
+    library keeps the raw pointer)."""
+    key = str(device)
+    t = _SAT.get(key)
+    if t is None:
+        t = _SAT[key] = torch.zeros(2, dtype=torch.int32, device=device)
+        check(lib().ce_stream16_set_counters(ptr(t)), "ce_stream16_set_counters")
+    return t

@@ -175,6 +175,16 @@ __device__ __forceinline__ void quick_gelu_both(float x, float& g, float& d) {
     d = __builtin_fmaf(1.702f * g, 1.0f - s, s);
 }
 
+// ---- fp16-stream saturation counters (runtime.cpp: the buffer registered with ce_stream16_set_counters, or null) ----
+// [0] forward residual stream: (wave, lane) slots of a LayerNorm forward that READ an element at the fp16 limit (every fp16
+//     store of the stream clamps to +-65504 and every stream row is read by a LayerNorm forward before anything else uses it);
+// [1] gradient stream: slots of a LayerNorm backward whose output, before the clamp, was at or beyond the limit (or not finite).
+unsigned int* ce_sat_counters();
+#define CE_F16_LIMIT 65504.0f
+__device__ __forceinline__ float absmax4(float m, f32x4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 // ---- optional event profiler (runtime.cpp); a no-op unless ce_profile_enable(1) ----
 int ce_prof_begin(int cls, double flops, double bytes, hipStream_t s);
 void ce_prof_end(int idx, hipStream_t s);

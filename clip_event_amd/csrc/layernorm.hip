@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      void* __restrict__ y, long ldy, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int M, int D, float eps,
-                                                     uint8_t* __restrict__ q8, long ldq, float* __restrict__ qscale) {
+                                                     uint8_t* __restrict__ q8, long ldq, float* __restrict__ qscale,
+                                                     unsigned int* __restrict__ sat) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR: the row descriptors are built from it
     const int rbase = (blockIdx.x * 4 + wave) * RPW;
     if (rbase >= M) return;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     // two reductions
     f32x4 v[RPW][IT], g[IT], bb[IT];
     float s[RPW];
+    float am = 0.f;                                        // fp16 stream: largest |element| this lane read (saturation telemetry)
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
         const int r = min(rbase + k, M - 1);               // a wave's surplus row repeats the last one (never stored)
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
         for (int i = 0; i < IT; ++i) {
             v[k][i] = cvt4<XT>(ld4_row<XT>(rx, i * 256 + lane * 4));      // 0 past D
             s[k] += (v[k][i][0] + v[k][i][1]) + (v[k][i][2] + v[k][i][3]);
+            if constexpr (XT == CE_T_F16) am = absmax4(am, v[k][i]);
         }
     }
     {
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
             if (q8) quant_row_from_regs<IT>(pk, lane, D, q8 + (long)r * ldq, qscale + r);       // wave-uniform
         }
     }
+    // an element AT the fp16 limit was clamped by the store that wrote it (or sits exactly on the edge): count it.  The branch
+    // comes last, behind every store of the kernel, so the straight-line row code above keeps its counted waits.
+    if constexpr (XT == CE_T_F16) {
+        if (sat && am >= CE_F16_LIMIT) atomicAdd(sat, 1u);
+    }
 }
 
 // dy: bf16 / fp32 / fp16-scaled stream.  dst row = rows ? rows[r] : r for x / dx (scatter form used
@@ -174,7 +182,8 @@ __global__ __launch_bounds__(64 * NW, CE_LN_BWD_MINB) void ln_bwd_kernel(const v
                                                          long lddxb, float* __restrict__ dw, float* __restrict__ db,
                                                          float* __restrict__ dxsum, const float* __restrict__ gscale_ptr,
                                                          int M, int D, uint8_t* __restrict__ q8, long ldq,
-                                                         float* __restrict__ qscale, float* __restrict__ partial) {
+                                                         float* __restrict__ qscale, float* __restrict__ partial,
+                                                         unsigned int* __restrict__ sat) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][D] + strip [3][D]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR: the row descriptors are built from it
     f32x4 aw[IT], ab[IT], ax[IT];
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(64 * NW, CE_LN_BWD_MINB) void ln_bwd_kernel(const v
     const float dy_mul = DYT == CE_T_F16 ? 1.0f / gscale : 1.0f;
     const float din_mul = DIT == CE_T_F16 ? 1.0f / gscale : 1.0f;
     const float out_mul = DOT == CE_T_F16 ? gscale : 1.0f;
+    float om = 0.f;                                               // fp16 gradient stream: largest |value| handed to the clamping store
     // rows in flight: PFD rows' raw loads (18 registers each at D = 768 on the fp16 stream) are outstanding while a row is reduced.
     // One is enough: 1, 2 and 3 measure the same 23.2-23.5 us per launch (tools/diag/ab_ln_occ.sh) -- with the loads no longer
     // serialised the row loop is bound by its ~350 vector instructions per row (two waves per SIMD), not by rows in flight.
@@ -270,8 +280,13 @@ __global__ __launch_bounds__(64 * NW, CE_LN_BWD_MINB) void ln_bwd_kernel(const v
             f32x4 o = (gy[i] - c1 - xh[i] * c2) * crs + din[i];
             o = (c < D) ? o : f32x4{0.f, 0.f, 0.f, 0.f};              // (xh is -mu * rstd past D)
             ax[i] += o;
-            if constexpr (DOT == CE_T_F16) st4_row<DOT, CE_LN_NT>(ro, c, o * out_mul);
-            else st4_row<DOT, CE_LN_NT>(ro, c, o);
+            if constexpr (DOT == CE_T_F16) {
+                const f32x4 os = o * out_mul;
+                om = absmax4(om, os);
+                st4_row<DOT, CE_LN_NT>(ro, c, os);
+            } else {
+                st4_row<DOT, CE_LN_NT>(ro, c, o);
+            }
             pkq[i] = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
             __builtin_amdgcn_raw_buffer_store_b64(pkq[i], rb, c * 2, 0, CE_LN_NT);
         }
@@ -288,6 +303,11 @@ __global__ __launch_bounds__(64 * NW, CE_LN_BWD_MINB) void ln_bwd_kernel(const v
 #pragma unroll
         for (int k = 0; k < PFD; ++k)
             if (r + k * stride < M) consume(pend[k], r + (k + PFD) * stride);
+    }
+    // saturation telemetry: a gradient that reached the fp16 limit (or is not finite) was clamped by its store.  !(om < limit) is
+    // also true for a NaN.
+    if constexpr (DOT == CE_T_F16) {
+        if (sat && !(om < CE_F16_LIMIT)) atomicAdd(sat + 1, 1u);
     }
     // dgamma / dbeta (/ dx column sums): per pass the waves park their partials in red[NW][D] and thread c folds column c into
     // strip[pass][c]; then every column gets ONE global atomic per workgroup, each workgroup starting at a different 64-column
@@ -382,16 +402,17 @@ extern "C" int ce_layernorm_fwd_q8(const void* x, int x_type, long ldx, const in
     const int rpw = D > 1024 ? 1 : (rpw_env == 2 ? 2 : 1);     // CE_LN_FWD_RPW=2: two rows per wave (one resident round at 12,800 rows): measured equal, 12.6 vs 12.7 us
     dim3 grid(ce_div_up(M, 4 * rpw)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    unsigned int* sat = ce_sat_counters();
     CeProfScope prof(CE_PROF_LN_FWD, 8.0 * M * D, (double)(ce_type_bytes(x_type) + ce_type_bytes(y_type)) * M * D, s);
     const int combo = x_type * 4 + y_type;      // the combinations the path uses; anything else is an argument error
 #define CALL(IT)                                                                                                              \
     switch (combo) {                                                                                                          \
-        case CE_T_F32 * 4 + CE_T_BF16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_BF16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_BF16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); break; \
-        case CE_T_F32 * 4 + CE_T_F32: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F32, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F32, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); break;   \
-        case CE_T_F32 * 4 + CE_T_F16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); break;   \
-        case CE_T_F16 * 4 + CE_T_BF16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_BF16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_BF16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); break; \
-        case CE_T_F16 * 4 + CE_T_F32: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F32, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F32, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); break;   \
-        case CE_T_F16 * 4 + CE_T_F16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale); break;   \
+        case CE_T_F32 * 4 + CE_T_BF16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_BF16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_BF16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); break; \
+        case CE_T_F32 * 4 + CE_T_F32: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F32, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F32, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); break;   \
+        case CE_T_F32 * 4 + CE_T_F16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F32, CE_T_F16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); break;   \
+        case CE_T_F16 * 4 + CE_T_BF16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_BF16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_BF16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); break; \
+        case CE_T_F16 * 4 + CE_T_F32: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F32, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F32, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); break;   \
+        case CE_T_F16 * 4 + CE_T_F16: if (rpw == 2 && IT <= 4) hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F16, (IT <= 4 ? 2 : 1)>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); else hipLaunchKernelGGL((ln_fwd_kernel<IT, CE_T_F16, CE_T_F16, 1>), grid, block, 0, s, x, ldx, rows, w, b, y, ldy, mean, rstd, M, D, eps, q8, ldq, qscale, sat); break;   \
         default: CE_CHECK_ARG(false, "ce_layernorm_fwd: element types x=%d y=%d are not built (x: f32 / f16, y: bf16 / f32 / f16)", x_type, y_type); \
     }
     LN_DISPATCH(D, CALL);
@@ -486,6 +507,7 @@ static int ln_bwd_launch(const void* dy, int dy_type, long lddy, const void* x, 
     dim3 grid(blocks), block(64 * nw);
     const size_t lds = (size_t)(nw + 3) * D * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    unsigned int* sat = ce_sat_counters();
     CeProfScope prof(CE_PROF_LN_BWD, 16.0 * M * D,
                      (double)(ce_type_bytes(dy_type) + ce_type_bytes(x_type) + (dx_in ? ce_type_bytes(dxin_type) : 0) +
                               ce_type_bytes(dx_type) + (dxb ? 2 : 0)) * M * D, s);
@@ -495,7 +517,7 @@ static int ln_bwd_launch(const void* dy, int dy_type, long lddy, const void* x, 
 #define LNB(DYT, XT, DIT, DOT) (((DYT * 4 + XT) * 4 + DIT) * 4 + DOT)
 #define LAUNCH(IT, DYT, XT, DIT, DOT)                                                                                         \
     hipLaunchKernelGGL((ln_bwd_kernel<IT, (IT <= 2 ? 16 : (IT <= 4 ? 8 : 4)), DYT, XT, DIT, DOT, true>), grid, block, lds, s, dy, lddy, \
-                       x, ldx, rows, mean, rstd, w, dx_in, dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, dxsum, gscale, M, D, q8, ldq, qscale, partial)
+                       x, ldx, rows, mean, rstd, w, dx_in, dx_out, lddx, (bf16_t*)dxb, lddxb, dw, db, dxsum, gscale, M, D, q8, ldq, qscale, partial, sat)
 #define CALL(IT)                                                                                                              \
     switch (combo) {                                                                                                          \
         case LNB(CE_T_BF16, CE_T_F32, CE_T_F32, CE_T_F32): LAUNCH(IT, CE_T_BF16, CE_T_F32, CE_T_F32, CE_T_F32); break;        \

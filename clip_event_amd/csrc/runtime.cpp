@@ -22,6 +22,15 @@ void ce_set_error(const char* fmt, ...) {
 extern "C" const char* ce_last_error(void) { return g_err; }
 extern "C" int ce_version(void) { return 1; }
 
+// ---- fp16 residual / gradient stream: saturation telemetry (include/clip_event_hip.h, ce_stream16_set_counters) ----
+// One process drives one GPU, so a single registered buffer serves every launch of the process.
+static unsigned int* g_sat_counters = nullptr;
+extern "C" int ce_stream16_set_counters(unsigned int* device_counters) {
+    g_sat_counters = device_counters;
+    return 0;
+}
+unsigned int* ce_sat_counters() { return g_sat_counters; }
+
 // ---- profiler: HIP events recorded on the launch stream around every launch of a class ----
 namespace {
 struct Rec { int cls; double flops, bytes; hipEvent_t e0, e1; };

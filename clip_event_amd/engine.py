@@ -4,8 +4,10 @@ global-norm clip to 1 and Adam (fused, optim.py).  With more than one rank the f
 all-gathered for a global-batch InfoNCE and parameter gradients are averaged (distributed.py)."""
 from __future__ import annotations
 
+import functools
 import logging
 import math
+import operator
 import os
 import sys
 from typing import Dict, Optional
@@ -13,7 +15,7 @@ from typing import Dict, Optional
 import torch
 
 from . import distributed as D
-from .functional import fused_contrastive_losses, fused_head_ok, logits_from_features
+from .functional import attach_lengths, fused_contrastive_losses, fused_head_ok, logits_from_features, tokens_to_device
 from .losses import CriterionAlignment, CriterionContrastive
 
 
@@ -72,14 +74,26 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
                grad_sync: Optional[D.GradSync] = None, criterion_ot: Optional[CriterionAlignment] = None,
                object_vec=None, entitytxt_vec=None, object_num=None, entitytxt_num=None,
                check_finite: bool = False, train_arg=None, bboxs=None, bbox_desc_vec=None,
-               bbox_label_vec=None) -> Dict[str, torch.Tensor]:
+               bbox_label_vec=None, text_lengths=None) -> Dict[str, torch.Tensor]:
     """One iteration of engine.py:48-95.  BASELINE config 4 is this call with ``criterion_ot`` + the object / entity
     tensors (``model.alignment``) and ``train_arg`` + boxes in ONE step, as the reference's forward takes them
     (model_clip.py:419-528, engine.py:57-63).  ``check_finite`` reproduces engine.py:70-81 (all-rank mean of the
     losses, ``.item()``, stop on a non-finite value); it costs the host synchronisation the reference pays every
-    step, so it is off by default."""
+    step, so it is off by default.
+
+    Token tensors may arrive on the HOST, as the reference's data loader yields them (engine.py:52 copies them): their
+    caption lengths are then taken on the host and travel with the asynchronous copy, so the text tower never reads
+    anything back from the device.  For tokens already on the GPU pass ``text_lengths`` (host integers, tokens up to and
+    including the EOT) or tag the tensor with ``functional.attach_lengths``; without either the lengths are read back
+    (one small synchronous copy per new tensor)."""
     wrapped = model
     model = _unwrap(model)
+    dev = next(model.parameters()).device
+    if text_lengths is not None:
+        attach_lengths(text, text_lengths)
+    text = tokens_to_device(text, dev)
+    if entitytxt_vec is not None:
+        entitytxt_vec = tokens_to_device(entitytxt_vec, dev)
     if grad_sync is None and wrapped is not model:
         grad_sync = wrapped.grad_sync
     if hasattr(optimizer, "zero_grad_first_touch"):
@@ -92,7 +106,7 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
     if model.alignment and criterion_ot is not None:
         image_features, text_features = model.sim_entity(object_vec, entitytxt_vec)       # engine.py:57-63
         loss_dict.update(criterion_ot(text_features, image_features, entitytxt_num, object_num))
-    losses = sum(loss for loss in loss_dict.values())                                      # engine.py:67
+    losses = functools.reduce(operator.add, loss_dict.values())                            # engine.py:67 (sum() would add an int 0 first: one more launch)
     if check_finite:
         reduced = D.reduce_dict({k: v.detach() for k, v in loss_dict.items()})
         loss_value = float(sum(v for v in reduced.values()))
@@ -101,6 +115,13 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
             logging.error(reduced)
             sys.exit(1)
     losses.backward()
+    if check_finite and getattr(model, "stream16", False):
+        # the fp16 streams clamp instead of overflowing, so a clipped activation / gradient never shows up as a non-finite
+        # loss: read the device-side clamp counters on the synchronisation this mode pays anyway, before the update is applied
+        sat_f, sat_g = model.stream16_saturation()
+        if sat_f or sat_g:
+            logging.error("fp16 stream saturated ({} forward, {} gradient slots), stopping training".format(sat_f, sat_g))
+            sys.exit(1)
     if hasattr(model, "_settle_first_touch"):
         model._settle_first_touch()    # a tower without a backward pass in this step: its weight gradients are zero
     if grad_sync is not None:

@@ -80,23 +80,86 @@ class TextPacking:
         self.rows, self.cu, self.src, self.sel, self._keep = rows, cu, src, sel, keep
 
 
-def text_packing(model, text) -> TextPacking:
+def attach_lengths(text: torch.Tensor, lengths) -> torch.Tensor:
+    """Tag a token tensor with its captions' HOST-side lengths (tokens up to and including the EOT = ``argmax + 1`` per row,
+    model_clip.py:415): the tokenizer / data loader knows them before the batch is copied to the GPU, and with them the text
+    tower sizes its launches without reading anything back from the device.  The tag lives on this tensor OBJECT (a
+    ``.clone()`` / ``.to()`` result needs its own)."""
+    text._ce_lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
+    return text
+
+
+def host_lengths(text_cpu: torch.Tensor) -> np.ndarray:
+    """``argmax(dim=-1) + 1`` of a CPU token matrix (first occurrence of the row maximum, as torch / numpy both define it)."""
+    return text_cpu.reshape(-1, text_cpu.shape[-1]).numpy().argmax(axis=-1).astype(np.int64) + 1
+
+
+def tokens_to_device(text: torch.Tensor, device) -> torch.Tensor:
+    """``text.to(device)`` of engine.py:52 for a token matrix that is still on the host: the copy is asynchronous (pinned
+    staging) and the result carries the host-side lengths (``attach_lengths``)."""
+    if text.is_cuda:
+        return text
+    lens = getattr(text, "_ce_lengths", None)
+    if lens is None:
+        lens = host_lengths(text)
+    out = text.to(device, non_blocking=True)
+    out._ce_lengths = lens
+    return out
+
+
+_PACK_CACHE_SLOTS = 8
+
+
+def _pack_key(text):
+    base = text._base if text._base is not None else text
+    return (id(base), text.storage_offset(), tuple(text.shape), tuple(text.stride()), text._version), base
+
+
+def text_packing(model, text, lengths=None) -> TextPacking:
     """Drop the rows after each caption's EOT (model_clip.py:415 takes the feature AT the EOT; with the causal mask of
     model_clip.py:377-384 later rows can reach neither that feature nor any gradient, so the result is unchanged).
-    The lengths have to reach the host (they size the launches): one 4*n-byte read-back per NEW token tensor; the
-    layout of a tensor seen before (same object, same version) is reused."""
+    The lengths size the launches, so the HOST needs them: from ``lengths`` / the tensor's ``attach_lengths`` tag (what a
+    tokenizer or data loader knows anyway: no device round trip), else by one 4*n-byte read-back per NEW token tensor (the
+    layout of a tensor seen before -- same storage, same version -- is reused; a small cache, so the fixed entity / role
+    tensors of config 4 stay cached beside the captions).  ``CE_CHECK_LENGTHS=1`` checks given lengths against the device."""
     cl, s = lib(), stream()
     n, T = text.shape
     dev = text.device
+    if lengths is None:
+        lengths = getattr(text, "_ce_lengths", None)
     cache = getattr(model, "_pack_cache", None)
-    if cache is not None and cache[0]() is text and cache[1] == text._version and cache[2] == model.pack_text:
-        return cache[3]
-    eot = _empty((n,), torch.int32, dev)
-    check(cl.ce_eot_rows(ptr(text), ptr(eot), c_long(n), c_int(T), s), "ce_eot_rows")
-    if not model.pack_text:
-        pk = TextPacking(n * T, None, None, eot)
+    if not isinstance(cache, dict):
+        cache = model._pack_cache = {}
+    key, base = _pack_key(text)
+    key = key + (bool(model.pack_text),)
+    hit = cache.get(key)
+    if hit is not None and hit[0]() is base:
+        return hit[1]
+    if lengths is not None:
+        lens = np.asarray(lengths, dtype=np.int64).reshape(-1)
+        if lens.shape[0] != n or lens.min() < 1 or lens.max() > T:
+            raise RuntimeError(f"text lengths must be {n} values in 1..{T}")
+        if os.environ.get("CE_CHECK_LENGTHS", "0") == "1":
+            dev_lens = (text.argmax(dim=-1) + 1).cpu().numpy()
+            if not np.array_equal(dev_lens, lens):
+                raise RuntimeError("attach_lengths / text_lengths disagree with argmax(text) + 1 on the device")
+        flat = np.arange(n, dtype=np.int64) * T + lens - 1
+        eot = None
     else:
-        flat = eot.cpu().numpy().astype(np.int64)                       # host sync on this stream only
+        eot = _empty((n,), torch.int32, dev)
+        check(cl.ce_eot_rows(ptr(text), ptr(eot), c_long(n), c_int(T), s), "ce_eot_rows")
+        flat = None
+    if not model.pack_text:
+        if eot is None:
+            meta = torch.empty(n, dtype=torch.int32, pin_memory=True)
+            meta.numpy()[:] = flat
+            eot = meta.to(dev, non_blocking=True)
+            pk = TextPacking(n * T, None, None, eot, keep=(meta,))
+        else:
+            pk = TextPacking(n * T, None, None, eot)
+    else:
+        if flat is None:
+            flat = eot.cpu().numpy().astype(np.int64)                   # host sync on this stream only
         lens = flat - np.arange(n, dtype=np.int64) * T + 1
         cu = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lens, out=cu[1:])
@@ -108,7 +171,10 @@ def text_packing(model, text) -> TextPacking:
         meta.numpy()[2 * n + 1:] = src
         meta_d = meta.to(dev, non_blocking=True)
         pk = TextPacking(R, meta_d[: n + 1], meta_d[2 * n + 1:], meta_d[n + 1: 2 * n + 1], keep=(meta, meta_d))
-    model._pack_cache = (weakref.ref(text), text._version, model.pack_text, pk)
+    if len(cache) >= _PACK_CACHE_SLOTS:
+        for k in [k for k, v in cache.items() if v[0]() is None] or [next(iter(cache))]:
+            cache.pop(k, None)
+    cache[key] = (weakref.ref(base), pk)
     return pk
 
 
@@ -180,7 +246,10 @@ class EncodeImageFn(torch.autograd.Function):
         if use_grid:
             rows, n = None, M
         else:                      # only the CLS row of each image is consumed (model_clip.py:256): pruned last block
-            rows = (torch.arange(B, device=dev, dtype=torch.int32) * T)
+            cache = model.__dict__.setdefault("_cls_rows", {})
+            rows = cache.get((B, T, dev))
+            if rows is None:                                   # built once per batch size (two torch launches otherwise)
+                rows = cache[(B, T, dev)] = (torch.arange(B, device=dev, dtype=torch.int32) * T)
             n = B
         xN = _empty((n, D), sdt, dev)
         check(cl.ce_tower_forward(ctypes.byref(model._vdesc), c_int(B), c_int(M), None, ptr(x0), ptr(lease.buf), ptr(xN),

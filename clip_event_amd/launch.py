@@ -20,6 +20,27 @@ import threading
 from typing import Dict, List, Optional, Sequence
 
 
+def visible_gpus() -> Optional[int]:
+    """GPUs this process may use, counted WITHOUT touching HIP (``torch.cuda.device_count()`` falls back to
+    ``hipGetDeviceCount`` -- which initialises the runtime in the parent -- when its amdsmi path fails): the visibility
+    variables first, then the KFD topology in sysfs (nodes with SIMDs are GPUs).  ``None`` when neither is readable."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except OSError:
+        return None
+
+
 def free_port() -> int:
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))

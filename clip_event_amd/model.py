@@ -165,6 +165,17 @@ class _Lease:
         self.release()
 
 
+class Stream16Saturation(FloatingPointError):
+    """An fp16 residual-stream activation or gradient-stream value hit the +-65504 clamp (``CLIP.stream16``)."""
+
+    def __init__(self, forward: int, gradient: int):
+        self.forward, self.gradient = forward, gradient
+        super().__init__(
+            f"fp16 stream saturated: {forward} forward-stream and {gradient} gradient-stream LayerNorm slots saw a value at the "
+            "+-65504 clamp; the affected step(s) used a clipped activation / gradient.  Set model.stream16 = False "
+            "(CE_STREAM16=0: fp32 streams, as the reference) or, for the gradient stream, lower CE_GRAD_TARGET.")
+
+
 # --------------------------------------------------------------------------- the model
 
 _GEMM_SUFFIXES = ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")
@@ -228,7 +239,7 @@ class CLIP(nn.Module):
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
                 "_tjobs_bwd", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
-                "_side_streams", "_main_stream", "_pack_cache", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_first_touch")
+                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_first_touch")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -348,6 +359,9 @@ class CLIP(nn.Module):
         self._flat, self._flat_grad, self._offsets, self._ranges = flat, flat_grad, offsets, ranges
         self._pmap = pmap
         self._trigger = torch.zeros(1, device=dev, requires_grad=True)
+        # fp16-stream saturation counters (include/clip_event_hip.h, ce_stream16_set_counters): [forward stream, gradient stream]
+        self._sat = L.sat_counters(dev)
+        self._sat_poll = None
         self._build_device_tables()
         self._versions = None
 
@@ -447,6 +461,36 @@ class CLIP(nn.Module):
         for n, p in self._pmap.items():
             if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + self._offsets[n] * 4:
                 p.grad = self._gview(n)
+
+    # ---- fp16 residual / gradient stream: saturation telemetry ------------------------------------------------
+    def stream16_saturation(self, reset: bool = False):
+        """``(forward, gradient)`` counts of fp16-stream values that hit the +-65504 clamp since the counters were last
+        reset (sticky device counters fed by every LayerNorm launch; synchronises).  Non-zero = some step computed with a
+        clipped activation or gradient -- something the reference's non-finite-loss exit (engine.py:79-82) cannot see."""
+        if getattr(self, "_sat", None) is None:
+            return (0, 0)
+        f, g = (int(v) for v in self._sat.cpu())
+        if reset:
+            self._sat.zero_()
+        return (f, g)
+
+    def poll_stream16_saturation(self):
+        """The same check without a host synchronisation: starts an asynchronous copy of the counters and examines the copy
+        the PREVIOUS call started (by then long complete).  Raises ``Stream16Saturation`` once a copy shows a clamp."""
+        if getattr(self, "_sat", None) is None or not self.stream16:
+            return
+        prev = self._sat_poll
+        if prev is not None and prev[1].query():
+            f, g = (int(v) for v in prev[0])
+            self._sat_poll = prev = None
+            if f or g:
+                raise Stream16Saturation(f, g)
+        if prev is None:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(self._sat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._sat_poll = (host, ev)
 
     # ---- bf16 operand copies + tower descriptors -------------------------------------------
     def _build_device_tables(self):
@@ -566,6 +610,7 @@ class CLIP(nn.Module):
         """Requantise from the bf16 operand copies (they have just been refreshed from the masters)."""
         if self._w8 is None:
             self._build_fp8_tables()
+        self.wait_transposes()            # with fp8 & 2 the quantiser reads the W^T copies an asynchronous rebuild may still be writing
         cl, s = lib(), stream()
         key = int(self.fp8) & 2
         if getattr(self, "_qjobs_key", None) != key:
@@ -679,11 +724,14 @@ class CLIP(nn.Module):
         from .functional import EncodeImageFn
         return EncodeImageFn.apply(image, self._trigger, self, bool(use_grid))
 
-    def encode_text(self, text):
-        """model_clip.py:398-417."""
+    def encode_text(self, text, lengths=None):
+        """model_clip.py:398-417.  ``lengths`` (optional, host integers: tokens up to and including each caption's EOT) spares
+        the text tower its one device read-back per new token tensor; ``functional.attach_lengths`` tags a tensor instead."""
         self._ready()
         self._note_pass("text")
-        from .functional import EncodeTextFn
+        from .functional import EncodeTextFn, attach_lengths
+        if lengths is not None:
+            attach_lengths(text, lengths)
         return EncodeTextFn.apply(text, self._trigger, self)
 
     def encode_both(self, image, text, use_grid: bool = False):
@@ -746,7 +794,7 @@ class CLIP(nn.Module):
         B, n_img, n_txt = img_obj.size(0), img_obj.size(1), txt_ent.size(1)
         image_features = self.encode_image(img_obj.reshape(B * n_img, img_obj.size(2), img_obj.size(3), img_obj.size(4)))
         image_features = image_features.view(B, n_img, -1)
-        text_features = self.encode_text(txt_ent.reshape(B * n_txt, txt_ent.size(2)))
+        text_features = self.encode_text(txt_ent.reshape(B * n_txt, txt_ent.size(2)), getattr(txt_ent, "_ce_lengths", None))
         text_features = text_features.view(B, n_txt, -1)
         return image_features, text_features
 

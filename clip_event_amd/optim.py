@@ -5,6 +5,7 @@ synchronisation -- and the learning-rate schedules of utils.py:310-416 / build_l
 from __future__ import annotations
 
 import math
+import os
 from bisect import bisect_right
 from ctypes import c_float, c_int, c_long
 from typing import List, Sequence
@@ -34,6 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.model = model
         self.max_norm = max_norm
         self.step_count = 0
+        self.sat_poll_every = int(os.environ.get("CE_SAT_POLL_EVERY", "16"))     # 0 = never
         self.m = self.v = self.sumsq = None
         super().__init__([p for p in model.parameters() if p.requires_grad],
                          dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -99,6 +101,10 @@ class FusedAdam(torch.optim.Optimizer):
                                  c_float(self.max_norm or 0.0), c_float(lr), c_float(self.betas[0]), c_float(self.betas[1]),
                                  c_float(self.eps), c_float(self.weight_decay), c_int(self.step_count), s), "ce_adam_step")
         m.mark_operands_stale(mirror_fresh=True)
+        # fp16 streams: look at the clamp counters every few steps, without a synchronisation (the copy started by one poll is
+        # examined by the next); raises model.Stream16Saturation
+        if self.sat_poll_every and self.step_count % self.sat_poll_every == 0 and hasattr(m, "poll_stream16_saturation"):
+            m.poll_stream16_saturation()
 
     # ---- torch.optim.Adam-format state (checkpoint interop) ----
     def state_dict(self):

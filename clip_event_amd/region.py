@@ -80,6 +80,15 @@ class _RegionNCEFn(torch.autograd.Function):
         return dr, dd, dl, dls.reshape(()), None, None, None, None, None
 
 
+def _stack_rows(rows, dev):
+    """The role / label token rows of the usable boxes as one [n, T] matrix on the GPU.  Rows that are still on the host
+    (a data loader's CPU tensors) are stacked there, their lengths taken on the host, and copied once."""
+    from .functional import tokens_to_device
+    if all(not r.is_cuda for r in rows):
+        return tokens_to_device(torch.stack(rows), dev)
+    return torch.stack([r.to(dev) for r in rows])
+
+
 def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg: str):
     dev = grid_features.device
     pn = model.visual.patch_num
@@ -114,8 +123,8 @@ def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, tr
         return zero, zero
     boxes = torch.tensor(box_rows, dtype=torch.int32, device=dev)
     region = _BBoxPoolFn.apply(grid_features, boxes)                                  # [nbox, E]
-    desc_f = model.encode_text(torch.stack(descs).to(dev))                            # one tower pass for all roles
-    lab_f = model.encode_text(torch.stack(labs).to(dev)) if use_label else None
+    desc_f = model.encode_text(_stack_rows(descs, dev))                               # one tower pass for all roles
+    lab_f = model.encode_text(_stack_rows(labs, dev)) if use_label else None
     offsets = torch.tensor([g[0] for g in groups] + [groups[-1][0] + groups[-1][1]], dtype=torch.int32, device=dev)
     max_rows = max(n for _, n in groups)
     if max_rows > 16:

@@ -137,7 +137,7 @@ def default_tokenizer() -> BPETokenizer:
 
 
 def tokenize(texts: Union[str, Sequence[str]], context_length: int = 77) -> torch.LongTensor:
-    """``clip.tokenize`` (clip.py:168-201): ``[n, context_length]`` int64."""
+    """``clip.tokenize`` (clip.py:168-201): ``[n, context_length]`` int64 (on the host, as in the reference)."""
     if isinstance(texts, str):
         texts = [texts]
     tk = default_tokenizer()
@@ -149,4 +149,7 @@ def tokenize(texts: Union[str, Sequence[str]], context_length: int = 77) -> torc
             ids = ids[:context_length]
             ids[-1] = eot
         out[i, :len(ids)] = torch.tensor(ids, dtype=torch.long)
+    # host-side caption lengths (argmax + 1, the EOT being the largest id: model_clip.py:415) ride along as a tag, so the
+    # text tower of the HIP path never has to read them back from the GPU (functional.text_packing / tokens_to_device)
+    out._ce_lengths = out.numpy().argmax(axis=-1).astype("int64") + 1
     return out

@@ -229,6 +229,16 @@ int ce_cast_scaled(const void* x, int src_type, void* y, int dst_type, const flo
  * the growth the gradient may see on its way down the tower (target 64: 1024x; measured x17-34 in the ViT-B/32 text tower).  scratch: CE_GRAD_SCALE_SCRATCH floats. */
 #define CE_GRAD_SCALE_SCRATCH 256
 int ce_grad_scale(const float* x, long n, float target, float* scratch, float* scale, void* stream);
+/* Saturation telemetry of the fp16 streams.  The reference keeps both streams in fp32 (model_clip.py:190-200) and stops on a
+ * non-finite loss (engine.py:79-82); an fp16 store that clamps at +-65504 produces neither an inf nor a NaN, so the clamp is
+ * made visible instead: register a DEVICE buffer of two unsigned counters (NULL switches it off; one buffer per process = per
+ * GPU).  From then on every LayerNorm launch adds to them, sticky until the caller zeroes the buffer:
+ *   [0] forward stream: LayerNorm-forward (wave, lane) slots that read a residual-stream element at the fp16 limit -- every
+ *       stream row passes through a LayerNorm forward before anything else reads it, so no clamped store escapes;
+ *   [1] gradient stream: LayerNorm-backward slots whose output gradient * scale reached the limit (or was not finite)
+ *       before the clamping store.
+ * Non-zero means the step computed with a clipped activation / gradient: lower CE_GRAD_TARGET, or run the stream in fp32. */
+int ce_stream16_set_counters(unsigned int* device_counters);
 /* dst[r,c] += src[r,c] for c < cols (rows with different strides: real columns of a column-padded gradient) */
 int ce_add_cols(const float* src, long lds, float* dst, long ldd, int rows, int cols, void* stream);
 /* gather / scatter whole rows: dst[dst_rows?dst_rows[i]:i] = src[src_rows?src_rows[i]:i], 16-byte granules */
