@@ -70,6 +70,9 @@ def parse():
                          "as SURVEY 8(d) c4: 1+U[0,6] objects, U[1,10] entities per image)")
     ap.add_argument("--train-arg", default=None, choices=["desc", "desc_type", "desc_type_text"],
                     help="BASELINE config 4: add the region / argument branch (U[1,4] roles per image, 25%% None boxes)")
+    ap.add_argument("--cu-hog", type=int, default=0,
+                    help="diagnostic (DESIGN 5): hold this many CUs busy-idle on a third stream for the length of every step "
+                         "(ce_cu_hog), as an RCCL ring's channel kernels would during the gradient all-reduce")
     ap.add_argument("--single-stream", action="store_true",
                     help="run both towers on one stream (the default overlaps them on two)")
     return ap.parse_args()
@@ -256,14 +259,16 @@ def main():
         from clip_event_amd.losses import CriterionAlignment
         model.set_hyps(True, True, False)
         obj, obj_num, ent, ent_num = S.synthetic_entities(B, R, 77, 49408, seed=1999 + rank)
-        extra.update(criterion_ot=CriterionAlignment(), object_vec=obj.to(dev), entitytxt_vec=ent.to(dev),
-                     object_num=obj_num.to(dev), entitytxt_num=ent_num.to(dev))
+        from clip_event_amd.functional import tokens_to_device
+        extra.update(criterion_ot=CriterionAlignment(), object_vec=obj.to(dev), entitytxt_vec=tokens_to_device(ent, dev),
+                     object_num=obj_num.to(dev), entitytxt_num=ent_num.to(dev))     # (tokens_to_device: .to(dev) + host-side lengths)
         log(f"alignment: object_vec {tuple(obj.shape)}, entitytxt_vec {tuple(ent.shape)}")
     if args.train_arg:
         boxes = S.synthetic_bboxes(B, seed=2999 + rank)
+        from clip_event_amd.functional import tokens_to_device
         extra.update(train_arg=args.train_arg, bboxs=boxes,
-                     bbox_desc_vec=[t.to(dev) for t in S.synthetic_role_texts(boxes, seed=3999 + rank)],
-                     bbox_label_vec=[t.to(dev) for t in S.synthetic_role_texts(boxes, seed=4999 + rank)])
+                     bbox_desc_vec=[tokens_to_device(t, dev) for t in S.synthetic_role_texts(boxes, seed=3999 + rank)],
+                     bbox_label_vec=[tokens_to_device(t, dev) for t in S.synthetic_role_texts(boxes, seed=4999 + rank)])
 
     # what one step pushes through the towers: images / captions of the main batch plus, in config 4, the object crops and
     # entity mentions of sim_entity (engine.py:57-63; padding slots are encoded too, as in the reference) and the role
@@ -292,10 +297,19 @@ def main():
     from clip_event_amd.functional import attach_lengths, host_lengths
     txt_lens = None if args.device_lengths else host_lengths(txt_host)
 
+    hog = {"stream": torch.cuda.Stream(device=dev) if args.cu_hog else None, "us": 0.0}
+
     def step():
         t = txt if args.reuse_captions else txt.clone()
         if txt_lens is not None:
             attach_lengths(t, txt_lens)
+        if args.cu_hog and hog["us"] > 0:
+            # the hog starts with the step (its stream waits for the previous step's end) and lasts one un-hogged step time
+            hog["stream"].wait_stream(torch.cuda.current_stream())
+            lib().ce_cu_hog(ctypes.c_int(args.cu_hog), ctypes.c_float(hog["us"]), ctypes.c_void_p(hog["stream"].cuda_stream))
+            out = train_step(model, crit, opt, img, t, yi, yt, ip, grad_sync=sync, **extra)
+            torch.cuda.current_stream().wait_stream(hog["stream"])
+            return out
         return train_step(model, crit, opt, img, t, yi, yt, ip, grad_sync=sync, **extra)
 
     def timed(nsteps):
@@ -317,6 +331,12 @@ def main():
 
     for _ in range(args.warmup):
         ld = step()
+    if args.cu_hog:          # calibrate the hog's duration on the un-hogged step, then warm up again with it
+        dt0, _ = timed(max(5, args.steps // 2))
+        hog["us"] = dt0 / max(5, args.steps // 2) * 1e6
+        log(f"cu hog: {args.cu_hog} CUs for {hog['us']:.0f} us per step (un-hogged step {hog['us'] / 1e3:.2f} ms)")
+        for _ in range(2):
+            step()
     dt, ld = timed(args.steps)
     loss = float(sum(v.detach() for v in ld.values()))
     log(f"timed region: {ms_per_step_tmp(dt, args.steps):.2f} ms/step")
@@ -420,7 +440,8 @@ def main():
                                      "live tokens SOT..EOT only: %.1f%% of B*77 rows (identical results, see DESIGN.md)"
                                      % (100.0 * live_frac)),
                        "fresh_captions_every_step": not args.reuse_captions,
-                       "alignment": bool(args.alignment), "train_arg": args.train_arg,
+                       "alignment": bool(args.alignment), "train_arg": args.train_arg, "cu_hog": args.cu_hog,
+                       "nt_pgrid": int(os.environ.get("CE_NT_PGRID", "256")),
                        "dense_text": dense},
             "roofline": roof, "cpu_baseline": cpu,
         }

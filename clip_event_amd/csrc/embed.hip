@@ -520,3 +520,34 @@ extern "C" int ce_copy_rows(const void* src, long src_stride_bytes, const int* s
     CE_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- CE_DIAG: a "CU hog" (sizing the contention between the GEMM grids and RCCL's kernels on one GPU) ----
+// `blocks` workgroups of 256 threads that each hold 96 KiB of LDS (so no two share a CU, and a CU that hosts one cannot take a
+// 156 KiB GEMM workgroup) and spin on the 100 MHz wall clock for `microseconds`: what a ring all-reduce's channels look
+// like to the rest of the chip, minus the memory traffic.  Every wave leaves the loop once the time is up (bounded spin).
+namespace {
+__global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks, unsigned int* sink) {
+    extern __shared__ unsigned int hog_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned int n = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        ++n;
+    }
+    hog_lds[threadIdx.x] = n;
+    if (sink && n == 0xffffffffu) sink[0] = hog_lds[(threadIdx.x + 1) & 255];      // keeps the LDS allocation and the loop alive
+}
+}  // namespace
+
+extern "C" int ce_cu_hog(int blocks, float microseconds, void* stream) {
+    CE_CHECK_ARG(blocks > 0 && blocks <= 256 && microseconds > 0.f && microseconds <= 1.0e6f, "ce_cu_hog: blocks 1..256, time up to 1 s");
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(cu_hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    const unsigned long long ticks = (unsigned long long)(microseconds * 100.0f);      // s_memrealtime counts at 100 MHz
+    hipLaunchKernelGGL(cu_hog_kernel, dim3(blocks), dim3(256), 96 * 1024, (hipStream_t)stream, ticks, (unsigned int*)nullptr);
+    CE_LAUNCH_CHECK();
+    return 0;
+}

@@ -80,22 +80,37 @@ class _RegionNCEFn(torch.autograd.Function):
         return dr, dd, dl, dls.reshape(()), None, None, None, None, None
 
 
-def _stack_rows(rows, dev):
+def _stack_rows(rows, lens, dev):
     """The role / label token rows of the usable boxes as one [n, T] matrix on the GPU.  Rows that are still on the host
-    (a data loader's CPU tensors) are stacked there, their lengths taken on the host, and copied once."""
-    from .functional import tokens_to_device
+    (a data loader's CPU tensors) are stacked there, their lengths taken on the host, and copied once; rows on the GPU
+    carry their host-side lengths along when their per-image matrices were tagged (functional.attach_lengths)."""
+    from .functional import attach_lengths, tokens_to_device
     if all(not r.is_cuda for r in rows):
         return tokens_to_device(torch.stack(rows), dev)
-    return torch.stack([r.to(dev) for r in rows])
+    out = torch.stack([r.to(dev) for r in rows])
+    if all(l is not None for l in lens):
+        attach_lengths(out, lens)
+    return out
 
 
-def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg: str):
-    dev = grid_features.device
+class RegionPlan:
+    """Host-side layout of one batch's region branch (model_clip.py:430-455): the pooled boxes, the role / label token
+    matrices of the usable boxes, and the per-image groups."""
+    __slots__ = ("boxes", "descs", "labs", "offsets", "groups", "max_rows", "use_label", "use_role_text")
+
+
+def region_plan(model, bboxs, bbox_desc_vec, bbox_label_vec, train_arg: str, dev):
+    """Everything of the region branch that does not need a tower: ``None`` when no image has a usable box."""
     pn = model.visual.patch_num
     use_label = train_arg.startswith("desc_type")
     use_role_text = train_arg.startswith("desc_type_text")
     box_rows: List[List[int]] = []
-    descs, labs, groups = [], [], []
+    descs, labs, dlens, llens, groups = [], [], [], [], []
+
+    def row_len(mat, i):
+        l = getattr(mat, "_ce_lengths", None)
+        return None if l is None else int(l[i])
+
     for image_idx, bbox_image in enumerate(bboxs):
         start = len(box_rows)
         last = None
@@ -108,28 +123,50 @@ def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, tr
             x0, y0, x1, y1 = max(0, min(x0, pn)), max(0, min(y0, pn)), max(0, min(x1, pn)), max(0, min(y1, pn))
             box_rows.append([image_idx, x0, y0, max(x1, x0), max(y1, y0)])
             descs.append(bbox_desc_vec[image_idx][bbox_id])
+            dlens.append(row_len(bbox_desc_vec[image_idx], bbox_id))
             if use_label:
                 labs.append(bbox_label_vec[image_idx][bbox_id])
+                llens.append(row_len(bbox_label_vec[image_idx], bbox_id))
         n = len(box_rows) - start
         if n == 0 or last is None:      # model_clip.py:450-455
             del box_rows[start:]
             del descs[start:]
+            del dlens[start:]
             if use_label:
                 del labs[start:]
+                del llens[start:]
             continue
         groups.append((start, n))
-    zero = torch.zeros((), dtype=torch.float32, device=dev)
     if not groups:
+        return None
+    plan = RegionPlan()
+    plan.boxes = torch.tensor(box_rows, dtype=torch.int32, device=dev)
+    plan.descs = _stack_rows(descs, dlens, dev)
+    plan.labs = _stack_rows(labs, llens, dev) if use_label else None
+    plan.offsets = torch.tensor([g[0] for g in groups] + [groups[-1][0] + groups[-1][1]], dtype=torch.int32, device=dev)
+    plan.groups = len(groups)
+    plan.max_rows = max(n for _, n in groups)
+    if plan.max_rows > 16:
+        raise RuntimeError(f"{plan.max_rows} boxes in one image: the region InfoNCE kernel takes at most 16")
+    plan.use_label, plan.use_role_text = use_label, use_role_text
+    return plan
+
+
+def region_losses_from_features(model, grid_features, plan: RegionPlan, desc_f, lab_f):
+    """(loss_per_bbox, loss_per_arg) from the image grid and the role / label text features of ``plan``'s rows: one pooling
+    launch, then all images' n x n InfoNCE terms, both directions and the label / role-text variants, in one launch (and one
+    for the backward): launch count independent of the batch size (the reference loops over images, :456-488)."""
+    region = _BBoxPoolFn.apply(grid_features, plan.boxes)                             # [nbox, E]
+    return _RegionNCEFn.apply(region, desc_f, lab_f, model.logit_scale, plan.offsets, plan.groups, plan.max_rows,
+                              plan.use_label, plan.use_role_text)
+
+
+def region_losses(model, grid_features, bboxs, bbox_desc_vec, bbox_label_vec, train_arg: str):
+    dev = grid_features.device
+    plan = region_plan(model, bboxs, bbox_desc_vec, bbox_label_vec, train_arg, dev)
+    if plan is None:
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
         return zero, zero
-    boxes = torch.tensor(box_rows, dtype=torch.int32, device=dev)
-    region = _BBoxPoolFn.apply(grid_features, boxes)                                  # [nbox, E]
-    desc_f = model.encode_text(_stack_rows(descs, dev))                               # one tower pass for all roles
-    lab_f = model.encode_text(_stack_rows(labs, dev)) if use_label else None
-    offsets = torch.tensor([g[0] for g in groups] + [groups[-1][0] + groups[-1][1]], dtype=torch.int32, device=dev)
-    max_rows = max(n for _, n in groups)
-    if max_rows > 16:
-        raise RuntimeError(f"{max_rows} boxes in one image: the region InfoNCE kernel takes at most 16")
-    # all images' n x n InfoNCE terms, both directions and the label / role-text variants, in one launch (and one for
-    # the backward): launch count independent of the batch size (the reference loops over images, :456-488)
-    return _RegionNCEFn.apply(region, desc_f, lab_f, model.logit_scale, offsets, len(groups), max_rows, use_label,
-                              use_role_text)
+    desc_f = model.encode_text(plan.descs)                                            # one tower pass for all roles
+    lab_f = model.encode_text(plan.labs) if plan.use_label else None
+    return region_losses_from_features(model, grid_features, plan, desc_f, lab_f)

@@ -455,6 +455,11 @@ void ce_gemm_nt_tune(int variant);
 /* tuning hook (tools/ only): 0 auto, 4/5/6/8 = tile height (x32 rows) of the 256-column kernel, 105 = 160x128 tile */
 void ce_gemm_nt_fp8_tune(int variant);
 
+/* "CU hog" (bench.py --cu-hog): `blocks` workgroups that each occupy one CU (96 KiB of LDS, 256 threads) for
+ * `microseconds` of wall time and do nothing -- what RCCL's channel kernels take away from the GEMM grids during a gradient
+ * all-reduce, so that the 8-GPU contention risk can be sized on one GPU.  Bounded spin: every wave exits when the time is up. */
+int ce_cu_hog(int blocks, float microseconds, void* stream);
+
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);
 /* one v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3): a_frags / b_frags 64 lanes x 32 bytes, scale_a / scale_b 64 ints (E8M0 in
