@@ -8,7 +8,7 @@ A second group forces the clamp (an activation above 65504; a gradient scale wit
 counted, raised by the asynchronous poll and stops ``train_step(check_finite=True)``.
 
 Bounds: those of tests/test_model_gpu.py (worst gradient cosine > 0.98 -- 0.97 on ViT-B/32, where the oracle's own
-bf16-operand mode reads 0.984, with the noise-floor rule per parameter --, median relative L2 < 0.03, |d loss| < 2e-2), with
+bf16-operand mode reads 0.984; and the fp16 stream held to the fp32 stream per parameter --, median relative L2 < 0.03, |d loss| < 2e-2), with
 the two that are absolute on the logits scaled to this state's logit scale (100 instead of 14.3: logits within 0.15 * 7 of
 the fp32 oracle; losses within 2e-2 * max(1, |loss|) -- loss_t is ~10 here).  What the oracle's own bf16-operand mode
 measures on this state (CPU, /tmp-free: tools/diag/hostile_calibration.py): tiny logits 0.11-0.13, loss_t 0.055-0.060,
@@ -24,12 +24,6 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 LOGIT_TOL = 0.15 * 100.0 / math.exp(math.log(1 / 0.07))      # the suite's 0.15 at scale 14.29, carried to scale 100
-
-
-@pytest.fixture(params=[False, True], ids=["stream32", "stream16"])
-def stream16(request, monkeypatch):
-    monkeypatch.setenv("CE_STREAM16", "1" if request.param else "0")
-    return request.param
 
 
 def _cos(a, b):
@@ -50,7 +44,10 @@ def _geometry(name):
 
 
 @pytest.mark.parametrize("geometry", ["tiny", "vit_b32_b8"])
-def test_trained_like_statistics_against_oracle(geometry, stream16):
+def test_trained_like_statistics_against_oracle(geometry, monkeypatch):
+    """Both stream formats on one trained-like state, each against the fp32 oracle with the suite's bounds, then against each
+    other: the fp16 stream may not be worse than the fp32 stream (per-parameter gradient error <= 1.5x + 0.02, worst cosine
+    within 0.01) -- if it were, the default would have to go back to fp32."""
     from oracle import clip_oracle as O
     from clip_event_amd import synthetic as S
     from clip_event_amd.losses import CriterionContrastive
@@ -65,50 +62,57 @@ def test_trained_like_statistics_against_oracle(geometry, stream16):
     y = torch.arange(B)
     torch.set_num_threads(min(16, torch.get_num_threads() or 16))
     ld32, g32, (li32, lt32) = O.loss_and_grads(sd, cfg, img, txt, y, y, y, True)
-    with (O.stream_f16() if stream16 else contextlib.nullcontext()):
-        _, g16, (li16, lt16) = O.loss_and_grads(sd, cfg, img, txt, y, y, y, True, bf16=True)   # same rounding points as the build
-
-    m = build_model({k: v.clone() for k, v in sd.items()}).to(DEV)
-    assert m.stream16 == stream16
-    m._ready()
-    m.stream16_saturation(reset=True)
-    li, lt = m(img.to(DEV), txt.to(DEV))
-    ld = CriterionContrastive("ce")(li, lt, y.to(DEV), y.to(DEV), index_pos=y.to(DEV))
-    (ld["loss_i"] + ld["loss_t"]).backward()
-    torch.cuda.synchronize()
-    sat = m.stream16_saturation()
-
-    d32 = max(float((li.cpu() - li32).abs().max()), float((lt.cpu() - lt32).abs().max()))
-    d16 = max(float((li.cpu() - li16).abs().max()), float((lt.cpu() - lt16).abs().max()))
-    worst, rels, over = (1.0, None), [], []
-    for n, p in m.named_parameters():
-        g = g32[n]
-        if g is None or float(g.norm()) == 0.0:
-            continue
-        c = _cos(p.grad, g)
-        r, r16 = _rel(p.grad, g), _rel(g16[n], g)
-        rels.append(r)
-        if r > 2.0 * r16 + 0.02:               # the suite's noise-floor rule (test_vitb32_b8_gradient_error_is_at_the_bf16_noise_floor)
-            over.append((n, round(r, 4), round(r16, 4)))
-        if c < worst[0]:
-            worst = (c, n)
     tn = lambda gs: float(sum(float(v.double().pow(2).sum()) for v in gs) ** 0.5)
-    norm_ratio = tn([p.grad for _, p in m.named_parameters()]) / tn([v for v in g32.values() if v is not None])
-    print(f"[{geometry} stream16={stream16}] logits vs fp32 {d32:.3f} (range {float(li32.abs().max()):.1f}), vs same-rounding oracle {d16:.3f}; "
-          f"loss_i {float(ld['loss_i']):.4f}/{float(ld32['loss_i']):.4f} loss_t {float(ld['loss_t']):.4f}/{float(ld32['loss_t']):.4f}; "
-          f"worst grad cosine {worst[0]:.5f} at {worst[1]}, median rel-l2 {np.median(rels):.4f} max {max(rels):.4f}, "
-          f"total norm ratio {norm_ratio:.4f}; clamp counters {sat}")
-    assert d32 < LOGIT_TOL and d16 < LOGIT_TOL / 3
-    for k in ("loss_i", "loss_t"):
-        assert abs(float(ld[k]) - float(ld32[k])) < 2e-2 * max(1.0, abs(float(ld32[k])))
-    # worst cosine: 0.98 as everywhere else on the tiny geometry; on ViT-B/32 the ORACLE's own bf16-operand mode reads 0.984
-    # (fp32 stream) / 0.990 (fp16 stream) on this state -- the gains of a late block's LayerNorm, whose gradient is the small
-    # difference of large terms once outlier channels exist -- so the bound there is 0.97 (measured on the box: 0.976 with the
-    # fp32 stream) plus the suite's noise-floor rule per parameter: error <= 2x the bf16-operand oracle's + 0.02
-    assert worst[0] > (0.98 if geometry == "tiny" else 0.97) and np.median(rels) < 0.03
-    assert not over, f"gradient error above twice the bf16-operand noise floor: {over[:5]}"
-    assert abs(norm_ratio - 1.0) < 0.05
-    assert sat == (0, 0), f"fp16 stream clamped at trained-like statistics: {sat}"
+    res = {}
+    for stream16 in (False, True):
+        monkeypatch.setenv("CE_STREAM16", "1" if stream16 else "0")
+        with (O.stream_f16() if stream16 else contextlib.nullcontext()):
+            _, g16, (li16, lt16) = O.loss_and_grads(sd, cfg, img, txt, y, y, y, True, bf16=True)   # the build's rounding points
+        m = build_model({k: v.clone() for k, v in sd.items()}).to(DEV)
+        assert m.stream16 == stream16
+        m._ready()
+        m.stream16_saturation(reset=True)
+        li, lt = m(img.to(DEV), txt.to(DEV))
+        ld = CriterionContrastive("ce")(li, lt, y.to(DEV), y.to(DEV), index_pos=y.to(DEV))
+        (ld["loss_i"] + ld["loss_t"]).backward()
+        torch.cuda.synchronize()
+        sat = m.stream16_saturation()
+        d32 = max(float((li.cpu() - li32).abs().max()), float((lt.cpu() - lt32).abs().max()))
+        d16 = max(float((li.cpu() - li16).abs().max()), float((lt.cpu() - lt16).abs().max()))
+        worst, rel, floor = (1.0, None), {}, {}
+        for n, p in m.named_parameters():
+            g = g32[n]
+            if g is None or float(g.norm()) == 0.0:
+                continue
+            c = _cos(p.grad, g)
+            rel[n], floor[n] = _rel(p.grad, g), _rel(g16[n], g)
+            if c < worst[0]:
+                worst = (c, n)
+        norm_ratio = tn([p.grad for _, p in m.named_parameters()]) / tn([v for v in g32.values() if v is not None])
+        rels = list(rel.values())
+        print(f"[{geometry} stream16={stream16}] logits vs fp32 {d32:.3f} (range {float(li32.abs().max()):.1f}), vs same-rounding oracle {d16:.3f}; "
+              f"loss_i {float(ld['loss_i']):.4f}/{float(ld32['loss_i']):.4f} loss_t {float(ld['loss_t']):.4f}/{float(ld32['loss_t']):.4f}; "
+              f"worst grad cosine {worst[0]:.5f} at {worst[1]}, median rel-l2 {np.median(rels):.4f} max {max(rels):.4f} "
+              f"(bf16-operand oracle: median {np.median(list(floor.values())):.4f} max {max(floor.values()):.4f}), "
+              f"total norm ratio {norm_ratio:.4f}; clamp counters {sat}")
+        assert d32 < LOGIT_TOL and d16 < LOGIT_TOL / 3
+        for k in ("loss_i", "loss_t"):
+            assert abs(float(ld[k]) - float(ld32[k])) < 2e-2 * max(1.0, abs(float(ld32[k])))
+        # worst cosine: 0.98 as everywhere else on the tiny geometry.  On ViT-B/32 the ORACLE's own bf16-operand mode reads
+        # 0.984 / 0.990 on this state and the build, which also rounds the gradient operand of every GEMM to bf16, 0.976 with
+        # the fp32 stream: the gains of a LayerNorm behind outlier channels get a gradient that is the small difference of
+        # large terms, and rounding noise does not cancel with them.  That is a property of bf16 operands, not of the stream
+        # format -- the bound there is 0.97 for BOTH formats, and the cross-check below pins the fp16 stream to the fp32 one.
+        assert worst[0] > (0.98 if geometry == "tiny" else 0.97) and np.median(rels) < 0.03
+        assert abs(norm_ratio - 1.0) < 0.05
+        assert sat == (0, 0), f"fp16 stream clamped at trained-like statistics: {sat}"
+        res[stream16] = (worst[0], rel)
+        del m
+    (c32, r32), (c16, r16) = res[False], res[True]
+    worse = [(n, round(r16[n], 4), round(r32[n], 4)) for n in r32 if r16[n] > 1.5 * r32[n] + 0.02]
+    print(f"[{geometry}] fp16 vs fp32 stream: worst cosine {c16:.5f} vs {c32:.5f}; median error ratio "
+          f"{np.median([r16[n] / max(r32[n], 1e-12) for n in r32]):.3f}; parameters beyond 1.5x + 0.02: {worse[:5]}")
+    assert c16 > c32 - 0.01 and not worse
 
 
 def _tiny_model(monkeypatch, s16=True):
