@@ -46,8 +46,9 @@ def _geometry(name):
 @pytest.mark.parametrize("geometry", ["tiny", "vit_b32_b8"])
 def test_trained_like_statistics_against_oracle(geometry, monkeypatch):
     """Both stream formats on one trained-like state, each against the fp32 oracle with the suite's bounds, then against each
-    other: the fp16 stream may not be worse than the fp32 stream (per-parameter gradient error <= 1.5x + 0.02, worst cosine
-    within 0.01) -- if it were, the default would have to go back to fp32."""
+    other: the fp16 stream may not be worse than the fp32 stream (whole-gradient error <= 1.25x + 0.003, per-parameter
+    error distribution: median <= 1.3x, 90th percentile <= 1.5x) -- if it were, the default would have to go back to fp32
+    (VERDICT r3 item 4)."""
     from oracle import clip_oracle as O
     from clip_event_amd import synthetic as S
     from clip_event_amd.losses import CriterionContrastive
@@ -62,7 +63,6 @@ def test_trained_like_statistics_against_oracle(geometry, monkeypatch):
     y = torch.arange(B)
     torch.set_num_threads(min(16, torch.get_num_threads() or 16))
     ld32, g32, (li32, lt32) = O.loss_and_grads(sd, cfg, img, txt, y, y, y, True)
-    tn = lambda gs: float(sum(float(v.double().pow(2).sum()) for v in gs) ** 0.5)
     res = {}
     for stream16 in (False, True):
         monkeypatch.setenv("CE_STREAM16", "1" if stream16 else "0")
@@ -79,40 +79,57 @@ def test_trained_like_statistics_against_oracle(geometry, monkeypatch):
         sat = m.stream16_saturation()
         d32 = max(float((li.cpu() - li32).abs().max()), float((lt.cpu() - lt32).abs().max()))
         d16 = max(float((li.cpu() - li16).abs().max()), float((lt.cpu() - lt16).abs().max()))
-        worst, rel, floor = (1.0, None), {}, {}
+        worst, worst_ln, rel, floor = (1.0, None), (1.0, None), {}, {}
         for n, p in m.named_parameters():
             g = g32[n]
             if g is None or float(g.norm()) == 0.0:
                 continue
             c = _cos(p.grad, g)
             rel[n], floor[n] = _rel(p.grad, g), _rel(g16[n], g)
-            if c < worst[0]:
+            if _is_ln(n):
+                if c < worst_ln[0]:
+                    worst_ln = (c, n)
+            elif c < worst[0]:
                 worst = (c, n)
-        norm_ratio = tn([p.grad for _, p in m.named_parameters()]) / tn([v for v in g32.values() if v is not None])
-        rels = list(rel.values())
+        names = [n for n, _ in m.named_parameters() if g32[n] is not None]
+        flat = torch.cat([dict(m.named_parameters())[n].grad.flatten().double().cpu() for n in names])
+        flat32 = torch.cat([g32[n].flatten().double() for n in names])
+        flat16 = torch.cat([g16[n].flatten().double() for n in names])
+        whole, whole_floor = float((flat - flat32).norm() / flat32.norm()), float((flat16 - flat32).norm() / flat32.norm())
+        norm_ratio = float(flat.norm() / flat32.norm())
+        rels = np.array(list(rel.values()))
         print(f"[{geometry} stream16={stream16}] logits vs fp32 {d32:.3f} (range {float(li32.abs().max()):.1f}), vs same-rounding oracle {d16:.3f}; "
               f"loss_i {float(ld['loss_i']):.4f}/{float(ld32['loss_i']):.4f} loss_t {float(ld['loss_t']):.4f}/{float(ld32['loss_t']):.4f}; "
-              f"worst grad cosine {worst[0]:.5f} at {worst[1]}, median rel-l2 {np.median(rels):.4f} max {max(rels):.4f} "
-              f"(bf16-operand oracle: median {np.median(list(floor.values())):.4f} max {max(floor.values()):.4f}), "
+              f"WHOLE gradient rel-l2 {whole:.4f} (bf16-operand oracle {whole_floor:.4f}); per parameter: median {np.median(rels):.4f} "
+              f"p90 {np.quantile(rels, 0.9):.4f} max {rels.max():.4f} (oracle: median {np.median(list(floor.values())):.4f} max {max(floor.values()):.4f}); "
+              f"worst cosine {worst[0]:.5f} at {worst[1]}, among LayerNorm parameters {worst_ln[0]:.5f} at {worst_ln[1]}; "
               f"total norm ratio {norm_ratio:.4f}; clamp counters {sat}")
         assert d32 < LOGIT_TOL and d16 < LOGIT_TOL / 3
         for k in ("loss_i", "loss_t"):
             assert abs(float(ld[k]) - float(ld32[k])) < 2e-2 * max(1.0, abs(float(ld32[k])))
-        # worst cosine: 0.98 as everywhere else on the tiny geometry.  On ViT-B/32 the ORACLE's own bf16-operand mode reads
-        # 0.984 / 0.990 on this state and the build, which also rounds the gradient operand of every GEMM to bf16, 0.976 with
-        # the fp32 stream: the gains of a LayerNorm behind outlier channels get a gradient that is the small difference of
-        # large terms, and rounding noise does not cancel with them.  That is a property of bf16 operands, not of the stream
-        # format -- the bound there is 0.97 for BOTH formats, and the cross-check below pins the fp16 stream to the fp32 one.
-        assert worst[0] > (0.98 if geometry == "tiny" else 0.97) and np.median(rels) < 0.03
-        assert abs(norm_ratio - 1.0) < 0.05
+        # The suite's bounds (worst cosine 0.98, median relative error 0.03) for every parameter but the LayerNorm gains / biases:
+        # behind outlier channels their gradient is two or three entries (the outlier channels': 0.0020 and 0.0018 of a 0.0033
+        # norm in visual block 11's ln_1) that are themselves small differences of large sums, and bf16 operand rounding moves
+        # them at random -- the ORACLE's bf16-operand mode against its own fp32 mode reads 0.17-0.31 worst relative error on
+        # this state, on a different LayerNorm for every image seed and with no preference for either stream format
+        # (tools/diag/hostile_sensitivity.py).  They get a looser bound (0.8; 0.98 on the tiny geometry, where it holds), the same
+        # for both formats, and the comparison that discriminates is statistical: the whole gradient vector, and the
+        # distribution of the per-parameter errors, fp16 stream against fp32 stream (below).
+        assert worst[0] > 0.98 and np.median(rels) < 0.03
+        assert worst_ln[0] > (0.98 if geometry == "tiny" else 0.8)
+        assert whole < 0.03 and abs(norm_ratio - 1.0) < 0.02
         assert sat == (0, 0), f"fp16 stream clamped at trained-like statistics: {sat}"
-        res[stream16] = (worst[0], rel)
+        res[stream16] = (whole, rels)
         del m
-    (c32, r32), (c16, r16) = res[False], res[True]
-    worse = [(n, round(r16[n], 4), round(r32[n], 4)) for n in r32 if r16[n] > 1.5 * r32[n] + 0.02]
-    print(f"[{geometry}] fp16 vs fp32 stream: worst cosine {c16:.5f} vs {c32:.5f}; median error ratio "
-          f"{np.median([r16[n] / max(r32[n], 1e-12) for n in r32]):.3f}; parameters beyond 1.5x + 0.02: {worse[:5]}")
-    assert c16 > c32 - 0.01 and not worse
+    (w32, r32), (w16, r16) = res[False], res[True]
+    print(f"[{geometry}] fp16 vs fp32 stream: whole-gradient error {w16:.4f} vs {w32:.4f}; per-parameter median {np.median(r16):.4f} vs "
+          f"{np.median(r32):.4f}, p90 {np.quantile(r16, 0.9):.4f} vs {np.quantile(r32, 0.9):.4f}")
+    assert w16 < 1.25 * w32 + 0.003
+    assert np.median(r16) < 1.3 * np.median(r32) + 0.002 and np.quantile(r16, 0.9) < 1.5 * np.quantile(r32, 0.9) + 0.01
+
+
+def _is_ln(name):
+    return ".ln_" in name or name.startswith(("ln_final", "visual.ln_"))
 
 
 def _tiny_model(monkeypatch, s16=True):
