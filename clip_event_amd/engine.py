@@ -68,6 +68,29 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
     return loss_dict
 
 
+# How far the host may run ahead of the GPU.  Nothing in a step needs the host to wait (with host-side caption lengths the text
+# tower no longer reads anything back), but an unthrottled host queues many steps deep -- and measured SLOWER: 12.8-12.9 against
+# 12.5 ms/step with the per-step read-back, which happened to hold the host one step behind.  CE_STEPS_AHEAD (default 1) keeps that
+# distance explicitly: before enqueueing step n the host waits for the end of step n - CE_STEPS_AHEAD - ... see DESIGN 4.
+_STEPS_AHEAD = int(os.environ.get("CE_STEPS_AHEAD", "1"))
+
+
+def _throttle(model):
+    if _STEPS_AHEAD <= 0 or not torch.cuda.is_available():
+        return
+    evs = model.__dict__.setdefault("_step_events", [])
+    while len(evs) >= _STEPS_AHEAD:
+        evs.pop(0).synchronize()
+
+
+def _mark_step_end(model):
+    if _STEPS_AHEAD <= 0 or not torch.cuda.is_available():
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    model.__dict__.setdefault("_step_events", []).append(ev)
+
+
 def _cat_tokens(parts):
     """One [n, T] token matrix for one text-tower pass; the host-side lengths travel along when every part has them."""
     if len(parts) == 1:
@@ -162,6 +185,7 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
     wrapped = model
     model = _unwrap(model)
     dev = next(model.parameters()).device
+    _throttle(model)
     if text_lengths is not None:
         attach_lengths(text, text_lengths)
     text = tokens_to_device(text, dev)
@@ -208,4 +232,5 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
     if grad_sync is not None:
         grad_sync.finish()             # no-op when the autograd final callback has already run it
     optimizer.step()                                                                       # clip + Adam
+    _mark_step_end(model)
     return loss_dict

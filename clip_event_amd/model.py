@@ -239,7 +239,7 @@ class CLIP(nn.Module):
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
                 "_tjobs_bwd", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
-                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_first_touch")
+                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "_step_events", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_first_touch")
 
     def __getstate__(self):
         state = dict(self.__dict__)
