@@ -69,10 +69,12 @@ def contrastive_step_losses(model, criterion: CriterionContrastive, image, text,
 
 
 # How far the host may run ahead of the GPU.  Nothing in a step needs the host to wait (with host-side caption lengths the text
-# tower no longer reads anything back), but an unthrottled host queues many steps deep -- and measured SLOWER: 12.8-12.9 against
-# 12.5 ms/step with the per-step read-back, which happened to hold the host one step behind.  CE_STEPS_AHEAD (default 1) keeps that
-# distance explicitly: before enqueueing step n the host waits for the end of step n - CE_STEPS_AHEAD - ... see DESIGN 4.
-_STEPS_AHEAD = int(os.environ.get("CE_STEPS_AHEAD", "1"))
+# tower no longer reads anything back), but an unthrottled host queues the whole run and that measured SLOWER: 12.93-12.94
+# ms/step against 12.48-12.56 with the per-step read-back (which happened to hold the host about a step behind), same box.
+# CE_STEPS_AHEAD = n (default 2; 0 = unlimited) makes the distance explicit: before enqueueing a step the host waits for the
+# end of the step n before it.  Same-box A/B: n = 1 12.76-13.0 (the GPU drains at every step boundary), n = 2 / 3 / 4 12.50-12.56
+# (second box 12.28-12.34, all three equal).
+_STEPS_AHEAD = int(os.environ.get("CE_STEPS_AHEAD", "2"))
 
 
 def _throttle(model):
