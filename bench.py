@@ -211,6 +211,13 @@ def main():
         local_rank = 0                              # ranks on one device, so the rehearsal runs the collectives on gloo
         os.environ.setdefault("CE_DIST_BACKEND", "gloo")
     force = os.environ.get("CE_FORCE_COLLECTIVES", "0") == "1"    # one rank, but through every RCCL call
+    real_stdout = None
+    if W > 1 or force:
+        # RCCL prints a version banner on STDOUT when its first communicator comes up: keep the contract (ONE JSON line on
+        # stdout) by pointing fd 1 at stderr for the run and writing the result line to the saved descriptor
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
     if W > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:                          # single-rank rehearsal: any free port
@@ -445,7 +452,10 @@ def main():
                        "dense_text": dense},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
     if W > 1 or force:
         dist.destroy_process_group()
 
