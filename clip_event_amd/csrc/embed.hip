@@ -526,15 +526,16 @@ extern "C" int ce_copy_rows(const void* src, long src_stride_bytes, const int* s
 // 156 KiB GEMM workgroup) and spin on the 100 MHz wall clock for `microseconds`: what a ring all-reduce's channels look
 // like to the rest of the chip, minus the memory traffic.  Every wave leaves the loop once the time is up (bounded spin).
 namespace {
-__global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks, unsigned int* sink) {
+__global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks, unsigned int* sink, int mode) {
     extern __shared__ unsigned int hog_lds[];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned int n = 0;
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
-        __builtin_amdgcn_s_sleep(32);
-        ++n;
+        if (mode == 0) __builtin_amdgcn_s_sleep(32);
+        else if (mode == 1) __builtin_amdgcn_s_sleep(127);
+        ++n;                                                      // mode 2: busy spin
     }
-    hog_lds[threadIdx.x] = n;
+    hog_lds[threadIdx.x & 255] = n;
     if (sink && n == 0xffffffffu) sink[0] = hog_lds[(threadIdx.x + 1) & 255];      // keeps the LDS allocation and the loop alive
 }
 }  // namespace
@@ -547,7 +548,14 @@ extern "C" int ce_cu_hog(int blocks, float microseconds, void* stream) {
         attr = true;
     }
     const unsigned long long ticks = (unsigned long long)(microseconds * 100.0f);      // s_memrealtime counts at 100 MHz
-    hipLaunchKernelGGL(cu_hog_kernel, dim3(blocks), dim3(256), 96 * 1024, (hipStream_t)stream, ticks, (unsigned int*)nullptr);
+    // CE_HOG_LDS / CE_HOG_THREADS (diagnostics): footprint of one hog workgroup (default 96 KiB, 256 threads)
+    static const int hog_lds = getenv("CE_HOG_LDS") ? atoi(getenv("CE_HOG_LDS")) : 96 * 1024;
+    static const int hog_threads = getenv("CE_HOG_THREADS") ? atoi(getenv("CE_HOG_THREADS")) : 256;
+    static const int hog_mode = getenv("CE_HOG_MODE") ? atoi(getenv("CE_HOG_MODE")) : 0;     // 0 s_sleep 32, 1 s_sleep 127, 2 busy spin
+    static const int hog_chop = getenv("CE_HOG_CHOP") ? atoi(getenv("CE_HOG_CHOP")) : 1;     // the time as this many back-to-back launches
+    for (int c = 0; c < hog_chop; ++c)
+        hipLaunchKernelGGL(cu_hog_kernel, dim3(blocks), dim3(hog_threads), hog_lds < 1024 ? 1024 : hog_lds, (hipStream_t)stream,
+                           ticks / hog_chop, (unsigned int*)nullptr, hog_mode);
     CE_LAUNCH_CHECK();
     return 0;
 }

@@ -2121,7 +2121,15 @@ int force_tm() {   // CE_GEMM_TM / ce_gemm_nt_tune(): 3..8 = tile height (x32 ro
 // K = 512, scales with K): one round of 32*TM-row tiles on the 256 CUs costs 28 + 10*TM (the K loop is
 // LDS-read bound: a fixed share for the 256-column B fragments plus TM A fragments per k-step); the
 // 160x256x32 kernel keeps two workgroups per CU: a co-resident pair costs 146, a lone one 78.
-inline long nt256_cost(long tiles, int tm) { return ((tiles + 255) / 256) * (28 + 10 * tm); }
+// CU budget of the NT launch policies (ce_gemm_set_cu_budget / CE_GEMM_CUS, default 256 = the whole chip).  Every NT kernel here
+// puts ONE 156 KiB workgroup on a CU and sizes its grid to fill the chip exactly once (one-round launches: 226-240 tiles;
+// persistent launches: 256 workgroups), so a single CU held by another stream's kernel -- an RCCL channel during a gradient
+// all-reduce -- leaves one workgroup without a home until a whole tile list has finished: measured with a 1-CU "hog"
+// (ce_cu_hog) every such launch takes 1.6-1.75x as long.  A budget below 256 sizes the one-round and the persistent
+// grids for that many CUs, so that the rest may be taken.
+int g_cus = getenv("CE_GEMM_CUS") ? atoi(getenv("CE_GEMM_CUS")) : 256;
+inline int cu_budget() { return g_cus >= 32 && g_cus <= 256 ? g_cus : 256; }
+inline long nt256_cost(long tiles, int tm) { return ((tiles + cu_budget() - 1) / cu_budget()) * (28 + 10 * tm); }
 inline long nt32_cost(long tiles) {
     const long n = (tiles + 255) / 256;
     return (n / 2) * 146 + (n % 2) * 78;
@@ -2233,7 +2241,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         static int policy = getenv("CE_NT_POLICY") ? atoi(getenv("CE_NT_POLICY")) : 113;
         const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
         const bool half = f == 104 || (f >= 203 && f <= 205) ||
-                          (f == 0 && (half_tiles <= 512 || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
+                          (f == 0 && (half_tiles <= 2 * cu_budget() || (policy & 8)) && ((policy & 1) && !use32 || (policy & 2) && use32));
         // the loader-wave kernels address their epilogue operands with 32-bit buffer offsets (EpiBuf): every one must span < 2 GiB
         const auto span = [&](long ld, long esz) { return (long)a.M * ld * esz; };
         const bool fits31 = span(a.ldo, epi_out_bytes(EPI)) < (1l << 31) && span(a.ldo2, 2) < (1l << 31) && span(a.ldaux, 2) < (1l << 31) &&
@@ -2274,7 +2282,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                 long bc = -1;
                 for (int tm = 5; tm >= 3; --tm) {
                     const long tiles = (long)ce_div_up(a.M, 32 * tm) * a.tiles_n;
-                    const long cost = ((tiles + 255) / 256) * (32 * tm + 48);
+                    const long cost = ((tiles + cu_budget() - 1) / cu_budget()) * (32 * tm + 48);
                     if (bc < 0 || cost < bc) { bc = cost; ptm = tm; }
                 }
             }
@@ -2293,7 +2301,8 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             // CE_NT_PGRID workgroups walk the tile list (default 256 = one per CU).  More, shorter lists = finer scheduling
             // granularity when some CUs are held by another stream's kernels (or by RCCL): a workgroup that starts late then
             // delays the launch by a shorter list.
-            static const int pgrid = getenv("CE_NT_PGRID") ? atoi(getenv("CE_NT_PGRID")) : 256;
+            static const int pgrid_env = getenv("CE_NT_PGRID") ? atoi(getenv("CE_NT_PGRID")) : 0;
+            const int pgrid = pgrid_env > 0 ? pgrid_env : cu_budget();
             const dim3 grid((unsigned)(tiles < pgrid ? tiles : pgrid)), block(64 * (8 + N4_LOADERS));
             prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 6);
             switch (ptm) {
@@ -2308,7 +2317,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             if (lw_tm >= 3 && lw_tm <= 5) ltm = lw_tm;
             else
                 for (int tm = 4; tm >= 3; --tm)
-                    if ((long)ce_div_up(a.M, 32 * tm) * a.tiles_n <= 256) ltm = tm;
+                    if ((long)ce_div_up(a.M, 32 * tm) * a.tiles_n <= cu_budget()) ltm = tm;
             a.tiles_m = ce_div_up(a.M, 32 * ltm);
             const dim3 grid(a.tiles_m * a.tiles_n), block(64 * (8 + N4_LOADERS));
             switch (ltm) {
@@ -2401,10 +2410,10 @@ int launch_nt_f8(NTArgs a, hipStream_t stream) {
     a.tiles_n = ce_div_up(a.N, N4_BN);
     const long half_tiles = (long)ce_div_up(a.M, 160) * ce_div_up(a.N, 128);
     const dim3 block(64 * (8 + N4_LOADERS));
-    if (half_tiles <= 512) {                       // one resident round of 160 x 256 tiles
+    if (half_tiles <= 2 * cu_budget()) {           // one resident round of 160 x 256 tiles
         int ltm = 5;
         for (int tm = 4; tm >= 3; --tm)
-            if ((long)ce_div_up(a.M, 32 * tm) * a.tiles_n <= 256) ltm = tm;
+            if ((long)ce_div_up(a.M, 32 * tm) * a.tiles_n <= cu_budget()) ltm = tm;
         a.tiles_m = ce_div_up(a.M, 32 * ltm);
         const dim3 grid(a.tiles_m * a.tiles_n);
         switch (ltm) {
@@ -2417,14 +2426,14 @@ int launch_nt_f8(NTArgs a, hipStream_t stream) {
         long bc = -1;
         for (int tm = 4; tm >= 3; --tm) {
             const long tiles = (long)ce_div_up(a.M, 32 * tm) * a.tiles_n;
-            const long cost = ((tiles + 255) / 256) * (32 * tm + 48);
+            const long cost = ((tiles + cu_budget() - 1) / cu_budget()) * (32 * tm + 48);
             if (bc < 0 || cost < bc) { bc = cost; ptm = tm; }
         }
         a.tiles_m = ce_div_up(a.M, 32 * ptm);
         a.tile_strip = 0;
         a.tile_chunk = 0;
         const long tiles = (long)a.tiles_m * a.tiles_n;
-        const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
+        const dim3 grid((unsigned)(tiles < cu_budget() ? tiles : cu_budget()));
         switch (ptm) {
             case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3, 1>), grid, block, N4_LDS_BYTES, stream, a); break;
             default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1>), grid, block, N4_LDS_BYTES, stream, a); break;
@@ -2458,6 +2467,12 @@ extern "C" int ce__gemm_nt_fp8_lw(const void* A8, long lda, const float* sa, con
         case CE_EPI_GELUGRAD_BF16: return launch_nt_f8<CE_EPI_GELUGRAD_BF16>(a, s);
         default: return 1;
     }
+}
+
+extern "C" int ce_gemm_set_cu_budget(int cus) {
+    CE_CHECK_ARG(cus == 0 || (cus >= 32 && cus <= 256), "ce_gemm_set_cu_budget: 32..256 CUs, or 0 for the default (CE_GEMM_CUS / 256)");
+    g_cus = cus ? cus : (getenv("CE_GEMM_CUS") ? atoi(getenv("CE_GEMM_CUS")) : 256);
+    return 0;
 }
 
 extern "C" void ce_gemm_nt_tune(int variant) {

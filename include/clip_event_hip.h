@@ -455,6 +455,13 @@ void ce_gemm_nt_tune(int variant);
 /* tuning hook (tools/ only): 0 auto, 4/5/6/8 = tile height (x32 rows) of the 256-column kernel, 105 = 160x128 tile */
 void ce_gemm_nt_fp8_tune(int variant);
 
+/* CU budget of the NT GEMM launch policies: every kernel of the family puts ONE 156 KiB workgroup on a CU and sizes its grid to
+ * fill the chip exactly once, so a CU held by another stream's kernel (an RCCL channel during the gradient all-reduce,
+ * train.py:222-225's DDP) makes the launch wait for a second round.  `cus` < 256 sizes the one-round and the persistent grids
+ * for that many CUs and leaves the rest to whoever holds them; 0 restores the default (CE_GEMM_CUS, else 256).  Process-wide;
+ * call between steps. */
+int ce_gemm_set_cu_budget(int cus);
+
 /* "CU hog" (bench.py --cu-hog): `blocks` workgroups that each occupy one CU (96 KiB of LDS, 256 threads) for
  * `microseconds` of wall time and do nothing -- what RCCL's channel kernels take away from the GEMM grids during a gradient
  * all-reduce, so that the 8-GPU contention risk can be sized on one GPU.  Bounded spin: every wave exits when the time is up. */
