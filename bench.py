@@ -187,6 +187,64 @@ def mfma_util():
         return None
 
 
+class PowerSampler:
+    """Board power and shader clock from the amdgpu hwmon files of this rank's GPU, sampled in a thread while the timed steps
+    run: stored beside every bench line so that box-to-box spread (clock / power state of the part) can be told from a
+    regression.  Reading sysfs touches neither HIP nor the GPU's queues; silently empty where the files
+    are not there."""
+
+    def __init__(self, index: int = 0, period: float = 0.02):
+        import glob
+        self.files = {}
+        gpus = []
+        try:        # the hwmon directory of THIS device, by PCI address (a box shows every GPU of its host in sysfs)
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            gpus = sorted(glob.glob(f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*"))
+            index = 0
+        except Exception:
+            pass
+        if not gpus:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+            gpus = [c for c in cards if glob.glob(os.path.join(c, "power1_*"))]
+        if gpus:
+            base = gpus[min(index, len(gpus) - 1)]
+            for key, names in (("power_w", ("power1_average", "power1_input")), ("sclk_mhz", ("freq1_input",)),
+                               ("power_cap_w", ("power1_cap",)), ("temp_c", ("temp1_input",))):
+                for n in names:
+                    if os.path.exists(os.path.join(base, n)):
+                        self.files[key] = os.path.join(base, n)
+                        break
+        self.scale = {"power_w": 1e-6, "power_cap_w": 1e-6, "sclk_mhz": 1e-6, "temp_c": 1e-3}
+        self.period, self.samples, self._stop, self._th = period, {k: [] for k in self.files}, False, None
+
+    def _run(self):
+        while not self._stop:
+            for k, f in self.files.items():
+                try:
+                    self.samples[k].append(float(open(f).read().strip()) * self.scale[k])
+                except Exception:
+                    pass
+            time.sleep(self.period)
+
+    def start(self):
+        if self.files:
+            import threading
+            self._stop = False
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=1.0)
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1), "n": len(v)}
+        return out or None
+
+
 def ms_per_step_tmp(dt, steps):
     return dt / steps * 1e3
 
@@ -344,8 +402,16 @@ def main():
         log(f"cu hog: {args.cu_hog} CUs for {hog['us']:.0f} us per step (un-hogged step {hog['us'] / 1e3:.2f} ms)")
         for _ in range(2):
             step()
+    sampler = PowerSampler(local_rank)
+    sampler.start()
     dt, ld = timed(args.steps)
+    power = sampler.stop()
     loss = float(sum(v.detach() for v in ld.values()))
+    hog_mhz = None
+    if args.cu_hog:
+        lib().ce_cu_hog_clock_mhz.restype = ctypes.c_double
+        hog_mhz = round(float(lib().ce_cu_hog_clock_mhz()), 1)
+        log(f"cu hog: shader clock seen by the hog during the last step {hog_mhz} MHz")
     log(f"timed region: {ms_per_step_tmp(dt, args.steps):.2f} ms/step")
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = B * W * args.steps / dt
@@ -447,10 +513,11 @@ def main():
                                      "live tokens SOT..EOT only: %.1f%% of B*77 rows (identical results, see DESIGN.md)"
                                      % (100.0 * live_frac)),
                        "fresh_captions_every_step": not args.reuse_captions,
-                       "alignment": bool(args.alignment), "train_arg": args.train_arg, "cu_hog": args.cu_hog,
+                       "alignment": bool(args.alignment), "train_arg": args.train_arg, "cu_hog": args.cu_hog, "cu_hog_shader_clock_mhz": hog_mhz,
                        "nt_pgrid": int(os.environ.get("CE_NT_PGRID", "256")),
                        "dense_text": dense},
             "roofline": roof, "cpu_baseline": cpu,
+            "power_sample": power,      # board power / shader clock (hwmon) over the timed steps of rank 0
         }
         if real_stdout is not None:
             os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -528,7 +528,7 @@ extern "C" int ce_copy_rows(const void* src, long src_stride_bytes, const int* s
 namespace {
 __global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks, unsigned int* sink, int mode) {
     extern __shared__ unsigned int hog_lds[];
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
     unsigned int n = 0;
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
         if (mode == 0) __builtin_amdgcn_s_sleep(32);
@@ -536,9 +536,25 @@ __global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks, u
         ++n;                                                      // mode 2: busy spin
     }
     hog_lds[threadIdx.x & 255] = n;
-    if (sink && n == 0xffffffffu) sink[0] = hog_lds[(threadIdx.x + 1) & 255];      // keeps the LDS allocation and the loop alive
+    if (sink && threadIdx.x == 0 && blockIdx.x == 0) {       // shader-clock ticks and 100 MHz ticks this workgroup lived for
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        reinterpret_cast<unsigned long long*>(sink)[0] = c1 - c0;
+        reinterpret_cast<unsigned long long*>(sink)[1] = r1 - t0;
+        sink[4] = hog_lds[(threadIdx.x + 1) & 255];           // keeps the LDS allocation and the loop alive
+    }
 }
 }  // namespace
+
+static unsigned int* g_hog_sink = nullptr;
+// shader clock (MHz) the last hog's first workgroup saw over its lifetime: s_memtime ticks per 100 MHz s_memrealtime tick
+// (synchronises the device)
+extern "C" double ce_cu_hog_clock_mhz(void) {
+    if (!g_hog_sink) return 0.0;
+    unsigned long long h[2] = {0, 0};
+    hipDeviceSynchronize();
+    hipMemcpy(h, g_hog_sink, sizeof(h), hipMemcpyDeviceToHost);
+    return h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+}
 
 extern "C" int ce_cu_hog(int blocks, float microseconds, void* stream) {
     CE_CHECK_ARG(blocks > 0 && blocks <= 256 && microseconds > 0.f && microseconds <= 1.0e6f, "ce_cu_hog: blocks 1..256, time up to 1 s");
@@ -553,9 +569,10 @@ extern "C" int ce_cu_hog(int blocks, float microseconds, void* stream) {
     static const int hog_threads = getenv("CE_HOG_THREADS") ? atoi(getenv("CE_HOG_THREADS")) : 256;
     static const int hog_mode = getenv("CE_HOG_MODE") ? atoi(getenv("CE_HOG_MODE")) : 0;     // 0 s_sleep 32, 1 s_sleep 127, 2 busy spin
     static const int hog_chop = getenv("CE_HOG_CHOP") ? atoi(getenv("CE_HOG_CHOP")) : 1;     // the time as this many back-to-back launches
+    if (!g_hog_sink) hipMalloc(&g_hog_sink, 64);
     for (int c = 0; c < hog_chop; ++c)
         hipLaunchKernelGGL(cu_hog_kernel, dim3(blocks), dim3(hog_threads), hog_lds < 1024 ? 1024 : hog_lds, (hipStream_t)stream,
-                           ticks / hog_chop, (unsigned int*)nullptr, hog_mode);
+                           ticks / hog_chop, g_hog_sink, hog_mode);
     CE_LAUNCH_CHECK();
     return 0;
 }

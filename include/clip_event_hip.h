@@ -466,6 +466,9 @@ int ce_gemm_set_cu_budget(int cus);
  * `microseconds` of wall time and do nothing -- what RCCL's channel kernels take away from the GEMM grids during a gradient
  * all-reduce, so that the 8-GPU contention risk can be sized on one GPU.  Bounded spin: every wave exits when the time is up. */
 int ce_cu_hog(int blocks, float microseconds, void* stream);
+/* shader clock in MHz that the last hog's first workgroup saw over its lifetime (s_memtime ticks per 100 MHz s_memrealtime
+ * tick): what the chip clocked at under the load that ran beside the hog.  Synchronises the device. */
+double ce_cu_hog_clock_mhz(void);
 
 /* Debug probes: raw MFMA / transposed-LDS-read lane maps (tests/test_hip_probes.py). */
 int ce_probe_mfma(int shape, const void* a_frags, const void* b_frags, float* out, void* stream);
