@@ -18,6 +18,8 @@
 // phase 2 per 16-key tile computes dV^T = dO^T P and dK^T = Q^T dS from the LDS images.
 #include <mutex>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/clip_event_hip.h"
 
@@ -435,6 +437,15 @@ __device__ __forceinline__ void store_block(char* dst, const BlockRegs& b, int t
     }
 }
 
+// NS 16-query strips per wave (a workgroup = 4 waves = 64 NS queries): every K fragment and every transposed V fragment read
+// from LDS serves NS strips.  With one strip per wave the 20 resident waves of a CU each re-read the whole 16 KiB K / V block
+// for 16 queries -- 320 KiB of LDS reads per CU and key block, 2.5 k cycles at the 128 B/clk the LDS delivers, twice the
+// matrix-pipe time of the same step.  MEASURED (ViT-L/14@336, B = 32, same box, attention ms per step): two strips per wave are
+// SLOWER in the forward (3.27-3.58 vs 3.00-3.19) and in dK / dV with two key tiles (10.97 vs 9.9), slightly faster in dQ
+// (9.34 vs 9.49, 9.86 vs 9.96 for the whole backward) -- the 138-200 registers of the wider forms halve the resident waves and
+// these kernels live on occupancy (barriers, dependent exp chains), not on LDS bandwidth.  Defaults: forward 1, dQ 2, dK / dV 1;
+// every form is parity-tested (CE_ATTN_NS_FWD / CE_ATTN_NS / CE_ATTN_NK).
+template <int NS>
 __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
                                                             long ldo, float* __restrict__ lse, int L, int H, int D,
                                                             int causal, float scale) {
@@ -446,17 +457,25 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __rest
     const int qb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
     const bf16_t* base = qkv + (long)b * L * ld + h * HD;
     const int li = lane & 15, g = lane >> 4;
-    const int i = qb * LB + wave * 16 + li;
-    const int iq = min(i, L - 1);
-    bf16x8 qf[2];
+    constexpr int QB = LB * NS;                                // queries per workgroup
+    int i[NS];
+    bf16x8 qf[NS][2];
+    float m[NS], l[NS];                                        // m: running maximum of the RAW scores q.k
+    f32x4 acc[NS][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
-    float m = -INFINITY, l = 0.f;
-    f32x4 acc[4];
+    for (int s = 0; s < NS; ++s) {
+        i[s] = qb * QB + (wave * NS + s) * 16 + li;
+        const int iq = min(i[s], L - 1);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 2; ++ks) qf[s][ks] = *reinterpret_cast<const bf16x8*>(base + (long)iq * ld + ks * 32 + g * 8);
+        m[s] = -INFINITY;
+        l[s] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = scale * 1.4426950408889634f;             // scale * log2(e)
     const int nkb_all = (L + LB - 1) / LB;
-    const int nkb = causal ? min(nkb_all, qb + 1) : nkb_all;
+    const int nkb = causal ? min(nkb_all, (qb * QB + QB - 1) / LB + 1) : nkb_all;
     BlockRegs nk = load_block(base + D, ld, 0, L, tid), nv = load_block(base + 2 * D, ld, 0, L, tid);
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb) __syncthreads();
@@ -467,62 +486,86 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __rest
             nv = load_block(base + 2 * D, ld, (kb + 1) * LB, L, tid);
         }
         __syncthreads();
-        f32x4 s[4];
-        float bm = -INFINITY;
+        // Softmax on the RAW scores: m tracks the largest raw score (scale > 0 keeps the order) and every probability is ONE
+        // fma + v_exp_f32, exp2(s c - m c) with c = scale log2(e) -- the scaling multiply, the subtraction and (except in the
+        // blocks that hold keys past L, or under the causal mask) the per-element mask are gone.  These kernels are bound by
+        // their vector ALU work and their LDS reads, not by the matrix pipe (head_dim 64: 256 MFMA FLOPs per score against
+        // ~7 vector operations).
+        f32x4 sc[NS][4];
+        const bool need_mask = causal || (kb + 1) * LB > L;    // block-uniform
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 kf[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = kb * LB + t * 16 + g * 4 + r;
-                const bool ok = (j < L) && (!causal || j <= i);
-                s[t][r] = ok ? s[t][r] * scale : -INFINITY;
-                bm = fmaxf(bm, s[t][r]);
+            for (int s = 0; s < NS; ++s) {
+                sc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) sc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[s][ks], sc[s][t], 0, 0, 0);
             }
         }
-        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-        const float mn = fmaxf(m, bm);                        // finite from the first block on: key 0 is never masked
-        const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
-        float sum = 0.f;
+        bf16x8 pf[NS][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < NS; ++s) {
+            float bm = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[t][r] = (mn == -INFINITY) ? 0.f : __expf(s[t][r] - mn);
-                sum += s[t][r];
+            for (int t = 0; t < 4; ++t) {
+                if (need_mask) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = kb * LB + t * 16 + g * 4 + r;
+                        const bool ok = (j < L) && (!causal || j <= i[s]);
+                        sc[s][t][r] = ok ? sc[s][t][r] : -INFINITY;
+                    }
+                }
+                bm = fmaxf(fmaxf(bm, fmaxf(sc[s][t][0], sc[s][t][1])), fmaxf(sc[s][t][2], sc[s][t][3]));
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        l = l * alpha + sum;
-        m = mn;
+            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float mn = fmaxf(m[s], bm);                 // finite from the first block on: key 0 is never masked
+            const float alpha = (m[s] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m[s] - mn) * c2);
+            const float mc = mn * c2;
+            float sum = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] *= alpha;
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[s][t][r] = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[s][t][r], c2, -mc));
+                    sum += sc[s][t][r];
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l[s] = l[s] * alpha + sum;
+            m[s] = mn;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[s][ct] *= alpha;
+            pf[s][0] = pack8(sc[s][0], sc[s][1]);
+            pf[s][1] = pack8(sc[s][2], sc[s][3]);
+        }
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
-            bf16x8 pf = pack8(s[2 * sidx], s[2 * sidx + 1]);
             const char* vrow = sV + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf16x8 vf = tr_pair(vrow + ct * 32, vrow + ct * 32 + 16 * ROW);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s][sidx], acc[s][ct], 0, 0, 0);
             }
         }
     }
-    if (i < L) {
-        const float inv = 1.0f / l;
-        bf16_t* orow = o + ((long)b * L + i) * ldo + h * HD + 4 * g;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            u32x2 pk = {pack_bf2(acc[ct][0] * inv, acc[ct][1] * inv), pack_bf2(acc[ct][2] * inv, acc[ct][3] * inv)};
-            *reinterpret_cast<u32x2*>(orow + ct * 16) = pk;
+    for (int s = 0; s < NS; ++s) {
+        if (i[s] < L) {
+            const float inv = 1.0f / l[s];
+            bf16_t* orow = o + ((long)b * L + i[s]) * ldo + h * HD + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                u32x2 pk = {pack_bf2(acc[s][ct][0] * inv, acc[s][ct][1] * inv), pack_bf2(acc[s][ct][2] * inv, acc[s][ct][3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + ct * 16) = pk;
+            }
+            if (g == 0) lse[((long)b * H + h) * L + i[s]] = m[s] * scale + __logf(l[s]);
         }
-        if (g == 0) lse[((long)b * H + h) * L + i] = m + __logf(l);
     }
 }
 
@@ -555,32 +598,11 @@ __device__ __forceinline__ StripOps load_strip(const bf16_t* base, long ld, cons
     return s;
 }
 
-// P^T and dS^T of one 16-query strip against the 64 keys staged in sK / sV (accumulator layout: key 16t + 4g + r)
-__device__ __forceinline__ void strip_p_ds(const char* sK, const char* sV, const StripOps& q, int i, bool iok, int key0, int L,
-                                           int causal, float scale, int li, int g, f32x4 (&p)[4], f32x4 (&ds)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-            bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q.qf[ks], p[t], 0, 0, 0);
-            ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, q.df[ks], ds[t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = key0 + t * 16 + g * 4 + r;
-            const bool ok = iok && (j < L) && (!causal || j <= i);
-            const float pv = ok ? __expf(p[t][r] * scale - q.lse) : 0.f;
-            p[t][r] = pv;
-            ds[t][r] = pv * (ds[t][r] - q.dl) * scale;
-        }
-    }
-}
-
-// backward A: dQ (and its bias column sums), one workgroup per 64-query block
+// backward A: dQ (and its bias column sums), one workgroup per block of 64 NS queries; NS 16-query strips per wave share every
+// K / V fragment read (see attn_fwd_long_kernel).  Per probability one fma + v_exp_f32 (p = exp2(s c - lse log2 e), c = scale
+// log2 e); the softmax scale of dS is applied once to the finished dQ accumulators (a power of two: the same bits); the
+// validity / causal mask only where the key block needs it (block-uniform).
+template <int NS>
 __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                                const bf16_t* __restrict__ o, long ldo,
                                                                const bf16_t* __restrict__ dout, long lddo,
@@ -599,16 +621,25 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
     const bf16_t* ob = o + (long)b * L * ldo + h * HD;
     bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
     const int li = lane & 15, g = lane >> 4;
-    const int i = qb * LB + wave * 16 + li;
-    const bool iok = i < L;
-    const int iq = min(i, L - 1);
+    constexpr int QB = LB * NS;
     if (tid < 64) csum[tid] = 0.f;
-    const StripOps q = load_strip(base, ld, dob, lddo, ob, ldo, lse + ((long)b * H + h) * L, iq, g);
-    f32x4 acc[4];
+    const float c2 = scale * 1.4426950408889634f;
+    int i[NS];
+    bool iok[NS];
+    StripOps q[NS];
+    float lse2[NS];
+    f32x4 acc[NS][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS; ++s) {
+        i[s] = qb * QB + (wave * NS + s) * 16 + li;
+        iok[s] = i[s] < L;
+        q[s] = load_strip(base, ld, dob, lddo, ob, ldo, lse + ((long)b * H + h) * L, min(i[s], L - 1), g);
+        lse2[s] = q[s].lse * 1.4426950408889634f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int nkb_all = (L + LB - 1) / LB;
-    const int nkb = causal ? min(nkb_all, qb + 1) : nkb_all;
+    const int nkb = causal ? min(nkb_all, (qb * QB + QB - 1) / LB + 1) : nkb_all;
     BlockRegs nk = load_block(base + D, ld, 0, L, tid), nv = load_block(base + 2 * D, ld, 0, L, tid);
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb) __syncthreads();
@@ -619,48 +650,95 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
             nv = load_block(base + 2 * D, ld, (kb + 1) * LB, L, tid);
         }
         __syncthreads();
-        f32x4 p[4], ds[4];
-        strip_p_ds(sK, sV, q, i, iok, kb * LB, L, causal, scale, li, g, p, ds);
+        // dS^T / scale of every strip against the 64 keys staged in sK / sV (accumulator layout: key 16t + 4g + r).  A padded
+        // query row i >= L repeats row L - 1: finite values, zeroed once at the end, so only keys past L and the causal mask
+        // need the per-element mask.
+        const bool need_mask = causal || (kb + 1) * LB > L;
+        f32x4 ds[NS][4];
+        auto p_ds = [&](auto mask_tag) __attribute__((always_inline)) {      // the mask as a compile-time property of the block's code
+            constexpr bool MASK = decltype(mask_tag)::value;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf16x8 kf[2], vf[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    kf[ks] = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                    vf[ks] = *reinterpret_cast<const bf16x8*>(sV + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    f32x4 p = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], q[s].qf[ks], p, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], q[s].df[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(p[r], c2, -lse2[s]));
+                        if constexpr (MASK) {
+                            const int j = kb * LB + t * 16 + g * 4 + r;
+                            const bool ok = (j < L) && (!causal || j <= i[s]);
+                            pv = ok ? pv : 0.f;
+                        }
+                        ds[s][t][r] = pv * (dp[r] - q[s].dl);
+                    }
+                }
+            }
+        };
+        if (need_mask) p_ds(std::true_type{});
+        else p_ds(std::false_type{});
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {                 // dQ^T += K^T dS^T
-            bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
+            bf16x8 sf[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sf[s] = pack8(ds[s][2 * sidx], ds[s][2 * sidx + 1]);
             const char* krow = sK + (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf16x8 kf = tr_pair(krow + ct * 32, krow + ct * 32 + 16 * ROW);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf, acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf[s], acc[s][ct], 0, 0, 0);
             }
         }
     }
-    if (iok) {
-        bf16_t* qrow = dbase + (long)i * lddq + 4 * g;
+    if (bias_grad) __syncthreads();                            // csum zeroed
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            u32x2 pk = {pack_bf2(acc[ct][0], acc[ct][1]), pack_bf2(acc[ct][2], acc[ct][3])};
-            *reinterpret_cast<u32x2*>(qrow + ct * 16) = pk;
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[s][ct] = iok[s] ? acc[s][ct] * scale : f32x4{0.f, 0.f, 0.f, 0.f};   // the softmax scale of dS, once; padded queries: exact zeros
+        if (iok[s]) {
+            bf16_t* qrow = dbase + (long)i[s] * lddq + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                u32x2 pk = {pack_bf2(acc[s][ct][0], acc[s][ct][1]), pack_bf2(acc[s][ct][2], acc[s][ct][3])};
+                *reinterpret_cast<u32x2*>(qrow + ct * 16) = pk;
+            }
+        }
+        if (bias_grad) {                                       // block-uniform
+            float vals[16];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vals[ct * 4 + r] = acc[s][ct][r];
+            const float tot = row16_colsum(vals, li);
+            const int k = row16_colsum_index(li);
+            atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tot);
         }
     }
-    if (bias_grad) {                                           // block-uniform
-        float vals[16];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vals[ct * 4 + r] = acc[ct][r];
-        const float tot = row16_colsum(vals, li);
-        const int k = row16_colsum_index(li);
-        __syncthreads();                                       // csum zeroed
-        atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tot);
+    if (bias_grad) {
         __syncthreads();
         if (tid < 64) atomicAdd(bias_grad + h * HD + tid, csum[tid]);
     }
 }
 
-// backward B: dK, dV (and their bias column sums), one workgroup per 64-key block, one wave per 16-key tile.
-// Here the scores are formed UN-transposed, S[i][j] = Q K^T with the wave's 16 keys on the accumulator columns
-// (K, V rows of those keys stay in registers for the whole kernel), so P and dS leave the accumulators already in
-// the layout the second products need as B operands (contraction over the queries, in the permuted order the
-// transposed dO^T / Q^T reads match -- the forward kernel's P V trick with keys and queries swapped): no P / dS
-// images in LDS, only the Q and dO blocks (requested one block ahead) and 64 delta / log-sum-exp values.
+// backward B: dK, dV (and their bias column sums), one workgroup per block of 64 NK keys, NK 16-key tiles per wave.
+// Here the scores are formed UN-transposed, S[i][j] = Q K^T with the wave's keys on the accumulator columns (K, V rows of
+// those keys stay in registers for the whole kernel), so P and dS leave the accumulators already in the layout the second
+// products need as B operands (contraction over the queries, in the permuted order the transposed dO^T / Q^T reads match --
+// the forward kernel's P V trick with keys and queries swapped): no P / dS images in LDS, only the Q and dO blocks (requested
+// one block ahead) and 64 delta / log-sum-exp values.  Every Q / dO fragment read, plain and transposed, serves NK key tiles.
+template <int NK>
 __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                                 const bf16_t* __restrict__ o, long ldo,
                                                                 const bf16_t* __restrict__ dout, long lddo,
@@ -682,24 +760,31 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
     bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
     const float* lse_row = lse + ((long)b * H + h) * L;
     const int li = lane & 15, g = lane >> 4;
-    const int j = kb * LB + wave * 16 + li;                     // this lane's key (accumulator column)
-    const bool jok = j < L;
-    const int jq = min(j, L - 1);
+    constexpr int KB = LB * NK;                                 // keys per workgroup
+    int j[NK];                                                  // this lane's keys (accumulator columns)
+    bool jok[NK];
+    bf16x8 kf[NK][2], vf[NK][2];                                // B operands: K / V rows of key j
+    f32x4 av[NK][4], ak[NK][4];
     if (tid < 128) csum[tid] = 0.f;
-    bf16x8 kf[2], vf[2];                                        // B operands: K / V rows of key j
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(base + D + (long)jq * ld + ks * 32 + g * 8);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (long)jq * ld + ks * 32 + g * 8);
-    }
-    f32x4 av[4], ak[4];
+    for (int kt = 0; kt < NK; ++kt) {
+        j[kt] = kb * KB + (wave * NK + kt) * 16 + li;
+        jok[kt] = j[kt] < L;
+        const int jq = min(j[kt], L - 1);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        av[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ak[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[kt][ks] = *reinterpret_cast<const bf16x8*>(base + D + (long)jq * ld + ks * 32 + g * 8);
+            vf[kt][ks] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (long)jq * ld + ks * 32 + g * 8);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            av[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ak[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     const int nqb = (L + LB - 1) / LB;
-    const int qb0 = causal ? kb : 0;
+    const int qb0 = causal ? (kb * KB) / LB : 0;
+    const float c2 = scale * 1.4426950408889634f;               // scale * log2(e)
     const int il = wave * 16 + li;                              // the query this lane serves in the delta pass
     auto strip_row = [&](int qb) { return min(qb * LB + il, L - 1); };
     BlockRegs nq = load_block(base, ld, qb0 * LB, L, tid), nd = load_block(dob, lddo, qb0 * LB, L, tid);
@@ -710,6 +795,7 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
         no[0] = po[0]; no[1] = po[1];
         nlse = lse_row[strip_row(qb0)];
     }
+    const bool keys_past_L = (kb + 1) * KB > L;                 // workgroup-uniform
     for (int qb = qb0; qb < nqb; ++qb) {
         __syncthreads();                                       // previous block's Q / dO / delta consumed
         store_block(sQ, nq, tid);
@@ -737,71 +823,104 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
             dl += __shfl_xor(dl, 32, 64);
             if (g == 0) {
                 sDelta[il] = dl;
-                sLse[il] = lse_i;
+                sLse[il] = lse_i * 1.4426950408889634f;      // in log2 units: p = exp2(s c - lse log2 e)
             }
         }
         __syncthreads();
-        f32x4 p[4], ds[4];
+        // one fma + v_exp_f32 per probability; dS without the softmax scale (applied once to the finished dK); the validity /
+        // causal mask only in the blocks that need it: the last query block (padded queries repeat row L - 1 and must add
+        // nothing to dK / dV), a key block that reaches past L (its column sums must stay zero) and under the causal mask
+        const bool need_mask = causal || keys_past_L || (qb + 1) * LB > L;
+        f32x4 p[NK][4], ds[NK][4];
+        auto p_ds = [&](auto mask_tag) __attribute__((always_inline)) {      // the mask as a compile-time property of the block's code
+            constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                          // S and dP of queries 16 t .. 16 t + 15 against this wave's keys
-            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) {                      // S and dP of queries 16 t .. 16 t + 15 against this wave's keys
+                bf16x8 qa[2], da[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-                bf16x8 da = *reinterpret_cast<const bf16x8*>(sDO + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
-                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp, 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    qa[ks] = *reinterpret_cast<const bf16x8*>(sQ + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                    da[ks] = *reinterpret_cast<const bf16x8*>(sDO + (t * 16 + li) * ROW + (ks * 4 + g) * 16);
+                }
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + t * 16 + 4 * g);       // lse * log2(e)
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + t * 16 + 4 * g);
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) {
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kf[kt][ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks], vf[kt][ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c2, -l4[r]));
+                        if constexpr (MASK) {
+                            const int i = qb * LB + t * 16 + 4 * g + r;
+                            const bool ok = jok[kt] && (i < L) && (!causal || j[kt] <= i);
+                            pv = ok ? pv : 0.f;
+                        }
+                        p[kt][t][r] = pv;
+                        ds[kt][t][r] = pv * (dp[r] - d4[r]);
+                    }
+                }
             }
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + t * 16 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + t * 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = qb * LB + t * 16 + 4 * g + r;
-                const bool ok = jok && (i < L) && (!causal || j <= i);
-                const float pv = ok ? __expf(sc[r] * scale - l4[r]) : 0.f;
-                p[t][r] = pv;
-                ds[t][r] = pv * (dp[r] - d4[r]) * scale;
-            }
-        }
+        };
+        if (need_mask) p_ds(std::true_type{});
+        else p_ds(std::false_type{});
         // dV^T += dO^T P, dK^T += Q^T dS: contraction element jj of lane group g <-> query 32 s + 16 (jj>>2) + 4 g + (jj&3)
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
-            bf16x8 pf = pack8(p[2 * sidx], p[2 * sidx + 1]);
-            bf16x8 sf = pack8(ds[2 * sidx], ds[2 * sidx + 1]);
+            bf16x8 pf[NK], sf[NK];
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                pf[kt] = pack8(p[kt][2 * sidx], p[kt][2 * sidx + 1]);
+                sf[kt] = pack8(ds[kt][2 * sidx], ds[kt][2 * sidx + 1]);
+            }
             const int roff = (32 * sidx + 4 * g + (li >> 2)) * ROW + (4 * (li & 3)) * 2;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 bf16x8 dof = tr_pair(sDO + roff + ct * 32, sDO + roff + ct * 32 + 16 * ROW);
                 bf16x8 qf = tr_pair(sQ + roff + ct * 32, sQ + roff + ct * 32 + 16 * ROW);
-                av[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, av[ct], 0, 0, 0);
-                ak[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf, ak[ct], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) {
+                    av[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf[kt], av[kt][ct], 0, 0, 0);
+                    ak[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, sf[kt], ak[kt][ct], 0, 0, 0);
+                }
             }
         }
     }
-    if (jok) {
-        bf16_t* krow = dbase + (long)j * lddq + D + 4 * g;
-        bf16_t* vrow = dbase + (long)j * lddq + 2 * D + 4 * g;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            u32x2 pk = {pack_bf2(ak[ct][0], ak[ct][1]), pack_bf2(ak[ct][2], ak[ct][3])};
-            u32x2 pv = {pack_bf2(av[ct][0], av[ct][1]), pack_bf2(av[ct][2], av[ct][3])};
-            *reinterpret_cast<u32x2*>(krow + ct * 16) = pk;
-            *reinterpret_cast<u32x2*>(vrow + ct * 16) = pv;
+    for (int kt = 0; kt < NK; ++kt) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) ak[kt][ct] *= scale;    // the softmax scale of dS, once
+        if (jok[kt]) {
+            bf16_t* krow = dbase + (long)j[kt] * lddq + D + 4 * g;
+            bf16_t* vrow = dbase + (long)j[kt] * lddq + 2 * D + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                u32x2 pk = {pack_bf2(ak[kt][ct][0], ak[kt][ct][1]), pack_bf2(ak[kt][ct][2], ak[kt][ct][3])};
+                u32x2 pv = {pack_bf2(av[kt][ct][0], av[kt][ct][1]), pack_bf2(av[kt][ct][2], av[kt][ct][3])};
+                *reinterpret_cast<u32x2*>(krow + ct * 16) = pk;
+                *reinterpret_cast<u32x2*>(vrow + ct * 16) = pv;
+            }
+        }
+        if (bias_grad) {
+            float vk[16], vv[16];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vk[ct * 4 + r] = ak[kt][ct][r];
+                    vv[ct * 4 + r] = av[kt][ct][r];
+                }
+            const float tk = row16_colsum(vk, li), tv = row16_colsum(vv, li);
+            const int k = row16_colsum_index(li);
+            atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tk);
+            atomicAdd(&csum[64 + (k >> 2) * 16 + 4 * g + (k & 3)], tv);
         }
     }
     if (bias_grad) {
-        float vk[16], vv[16];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                vk[ct * 4 + r] = ak[ct][r];
-                vv[ct * 4 + r] = av[ct][r];
-            }
-        const float tk = row16_colsum(vk, li), tv = row16_colsum(vv, li);
-        const int k = row16_colsum_index(li);
-        atomicAdd(&csum[(k >> 2) * 16 + 4 * g + (k & 3)], tk);
-        atomicAdd(&csum[64 + (k >> 2) * 16 + 4 * g + (k & 3)], tv);
         __syncthreads();
         if (tid < 128) atomicAdd(bias_grad + (1 + (tid >> 6)) * D + h * HD + (tid & 63), csum[tid]);
     }
@@ -830,8 +949,14 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
         CE_CHECK_ARG((long)B * H <= 65535, "ce_attention_fwd: B*H = %ld exceeds the grid", (long)B * H);
         hipStream_t sl = (hipStream_t)stream;
         CeProfScope prof(CE_PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (4.0 * D), sl);
-        hipLaunchKernelGGL(attn_fwd_long_kernel, dim3((L + LB - 1) / LB, B * H), dim3(256), 0, sl, (const bf16_t*)qkv, ld,
-                           (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f);
+        // strips per wave (CE_ATTN_NS_FWD = 1 / 2, default 1): a workgroup takes 64 NS queries
+        static const int ns = getenv("CE_ATTN_NS_FWD") ? atoi(getenv("CE_ATTN_NS_FWD")) : 1;
+        if (ns == 1)
+            hipLaunchKernelGGL(attn_fwd_long_kernel<1>, dim3((L + LB - 1) / LB, B * H), dim3(256), 0, sl, (const bf16_t*)qkv, ld,
+                               (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f);
+        else
+            hipLaunchKernelGGL(attn_fwd_long_kernel<2>, dim3((L + 2 * LB - 1) / (2 * LB), B * H), dim3(256), 0, sl, (const bf16_t*)qkv, ld,
+                               (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f);
         CE_LAUNCH_CHECK();
         return 0;
     }
@@ -863,11 +988,22 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
         CE_CHECK_ARG((long)B * H <= 65535, "ce_attention_bwd: B*H = %ld exceeds the grid", (long)B * H);
         hipStream_t sl = (hipStream_t)stream;
         CeProfScope prof(CE_PROF_ATTN_BWD, 14.0 * B * H * (double)L * L * HD, 2.0 * (double)B * L * (8.0 * D), sl);
-        const dim3 grid((L + LB - 1) / LB, B * H);
-        hipLaunchKernelGGL(attn_bwd_long_dq_kernel, grid, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                           (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
-        hipLaunchKernelGGL(attn_bwd_long_dkv_kernel, grid, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                           (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+        // strips (dQ) / key tiles (dK, dV) per wave: CE_ATTN_NS, CE_ATTN_NK = 1 / 2 (default 2 / 1: see attn_fwd_long_kernel)
+        static const int ns = getenv("CE_ATTN_NS") ? atoi(getenv("CE_ATTN_NS")) : 2;
+        static const int nk = getenv("CE_ATTN_NK") ? atoi(getenv("CE_ATTN_NK")) : 1;
+        const dim3 grid1((L + LB - 1) / LB, B * H), grid2((L + 2 * LB - 1) / (2 * LB), B * H);
+        if (ns == 1)
+            hipLaunchKernelGGL(attn_bwd_long_dq_kernel<1>, grid1, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+        else
+            hipLaunchKernelGGL(attn_bwd_long_dq_kernel<2>, grid2, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+        if (nk == 1)
+            hipLaunchKernelGGL(attn_bwd_long_dkv_kernel<1>, grid1, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+        else
+            hipLaunchKernelGGL(attn_bwd_long_dkv_kernel<2>, grid2, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
         CE_LAUNCH_CHECK();
         return 0;
     }
