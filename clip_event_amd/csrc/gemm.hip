@@ -1134,230 +1134,6 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
 }
 
 // ------------------------------------------------------------------------------------------
-// PING-PONG persistent kernel for launches of several rounds of tiles with a SHORT contraction (N = 3d / 4d at K = d: twelve
-// K iterations per tile, where a tile of the kernels above spends as long in its epilogue and start-up as in its K loop, and
-// every wave of the CU is in the same phase at the same time -- matrix pipes idle under the epilogue, vector ALUs and the
-// store path idle under the K loop).  128x256x64 tiles, 8 waves x 256 VGPRs in TWO GROUPS of four (one wave of each group on
-// every SIMD), each wave a 64 x 128 block of its group's tile (128 accumulator registers).  The groups take the workgroup's
-// tiles alternately and run HALF A PERIOD apart: during the nk iterations in which group X multiplies tile s (A phase:
-// fragment reads + 64 MFMAs per stage, nothing else), group Y is in its B phase: it issues every LDS-DMA instruction of the
-// ring (12 per wave and stage, two stages ahead -- there are no dedicated loader waves) and, between them, works through the
-// epilogue of tile s-1, which it multiplied in the previous period, one 16 x 64 unit per iteration.  So on each SIMD the
-// epilogue's VALU / LDS / store instructions of one wave fill the issue slots the other wave's MFMAs leave free.
-//  * One barrier per iteration, executed by all eight waves (= "stage it has landed, stage it-1 has been read").  Whoever
-//    issued a stage waits for it (vmcnt is per wave): a group entering its A phase still owns the last two stages it issued
-//    and waits for them in its first two iterations.
-//  * vmcnt is hand-counted around the compiler's stores: every epilogue unit issues a FIXED number of buffer stores (SO)
-//    and no load at all -- the bias is the accumulators' initial value, loaded in the A phase -- so the wait in front of
-//    barrier `it` allows exactly the 12 DMAs of stage it+1 plus the stores of the units of the last two iterations.  Units
-//    end at least two iterations before the phase does (U = units per iteration = ceil(8 / (nk - 2))).
-//  * LDS: three 48 KiB stages + four 4 KiB epilogue transposition tiles (only one group is in its B phase at a time) =
-//    160 KiB exactly; the tiles are unpadded, 16-byte chunk c of row r lives at chunk c ^ r (conflict-free for the
-//    accumulator-layout ds_write_b128 and the row-layout ds_read_b128).
-// Epilogues: BF16, BIAS_BF16, BIAS_GELU (the forward's qkv and c_fc GEMMs).  Needs N % 256 == 0, K % 64 == 0, K >= 256.
-// ------------------------------------------------------------------------------------------
-constexpr int PP_BM = 128, PP_BN = 256;
-constexpr int PP_A_BYTES = PP_BM * 128;                       // 16 KiB: 128 bytes of the contraction per row
-constexpr int PP_STAGE_BYTES = (PP_BM + PP_BN) * 128;          // 48 KiB
-constexpr int PP_RING_BYTES = 3 * PP_STAGE_BYTES;             // 144 KiB
-constexpr int PP_SCRATCH_BYTES = 4096;                        // per B-phase wave: 16 rows x 64 fp32
-constexpr int PP_LDS_BYTES = PP_RING_BYTES + 4 * PP_SCRATCH_BYTES;   // 160 KiB
-constexpr int PP_PER = (PP_BM / 8 + PP_BN / 8) / 4;            // 12 LDS-DMA instructions per wave and stage
-
-template <int N>
-__device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int EPI, int U>
-__global__ __launch_bounds__(512) void gemm_nt128pp_kernel(NTArgs p) {
-    static_assert(EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_GELU, "ping-pong kernel: forward epilogues only");
-    constexpr int SO = EPI == CE_EPI_BIAS_GELU ? 4 : 2;          // buffer stores per epilogue unit (two 8-row slots x outputs)
-    constexpr int NUI = 8 / U;                                    // B-phase iterations that carry epilogue units
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3;
-    const int wm = w4 >> 1, wn = w4 & 1;
-    const PersistWalk walk = persist_walk(p, p.tiles_m * p.tiles_n);
-    const int n_my = walk.count;
-    const int nk = p.K / 64;                                      // >= NUI + 2 (host)
-    const int total = n_my * nk;
-    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem;
-
-    // ---- B phase, loads: instruction j = w4 + 4 i of a stage (8 rows x 128 B each; 16 of A, then 32 of B)
-    const int s_row = lane >> 3;
-    const int s_chunk = (lane & 7) ^ s_row;
-    const uint32_t vA0 = (uint32_t)((w4 * 8 + s_row) * p.lda * 2 + s_chunk * 16);
-    const uint32_t vB0 = (uint32_t)((w4 * 8 + s_row) * p.ldb * 2 + s_chunk * 16);
-    const uint32_t stepA = (uint32_t)(32 * p.lda * 2), stepB = (uint32_t)(32 * p.ldb * 2);
-    auto tile_coords = [&](int t, int& m0, int& n0) {
-        int tm, tn;
-        persist_coords(p, walk.first + t * walk.step, tm, tn);
-        m0 = tm * PP_BM;
-        n0 = tn * PP_BN;
-    };
-    auto desc = [&](int t, u32x4& rA, u32x4& rB) {
-        int m0, n0;
-        tile_coords(t, m0, n0);
-        rA = make_rsrc_words(p.A + (long)m0 * p.lda, (uint32_t)((long)min(p.M - m0, PP_BM) * p.lda * 2));
-        rB = make_rsrc_words(p.B + (long)n0 * p.ldb, (uint32_t)((long)min(p.N - n0, PP_BN) * p.ldb * 2));
-    };
-    auto issue = [&](const u32x4& rA, const u32x4& rB, int slot, int kt) {
-        const uint32_t base = lds0 + slot * PP_STAGE_BYTES + w4 * 1024;
-        const uint32_t kb = (uint32_t)(kt * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma16_bounds(rA, base + i * 4096, vA0 + i * stepA + kb);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dma16_bounds(rB, base + PP_A_BYTES + i * 4096, vB0 + i * stepB + kb);
-    };
-
-    // ---- A phase, fragments
-    const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
-    const int fa_base = (wm * 64 + f_row) * 128;
-    const int fb_base = PP_A_BYTES + (wn * 128 + f_row) * 128;
-    // ---- epilogue maps: accumulator layout (row lane & 15, columns 4 (lane >> 4) .. + 3 of each 16-column block) -> row layout
-    // (row lane >> 3 of an 8-row slot, 8 consecutive columns) through this wave's 16 x 64 fp32 tile, chunk c of row r at c ^ r
-    char* ebuf = smem + PP_RING_BYTES + w4 * PP_SCRATCH_BYTES;
-    const int e_r = lane >> 3, e_j = lane & 7;
-    const int pw_row = lane & 15, pw_g = lane >> 4;
-
-    f32x4 acc[4][8];
-    int slot = 0;                                                 // ring slot of the stage multiplied in this iteration (= it % 3)
-    u32x4 rA = {0u, 0u, 0u, 0u}, rB = rA, rA2 = rA, rB2 = rA;
-    if (grp == 1) {                                               // group 1 is the B group of slot 0: the ring's first two stages
-        desc(0, rA, rB);
-        issue(rA, rB, 0, 0);
-        issue(rA, rB, 1, 1);
-    }
-    for (int s = 0; s <= n_my; ++s) {
-        if ((s & 1) == grp) {
-            // ================= A phase: multiply tile s =================
-            if (s == n_my) break;
-            int m0, n0;
-            tile_coords(s, m0, n0);
-            {
-                const int cb = n0 + wn * 128 + 4 * pw_g;           // this lane's first column of block nt: cb + 16 nt
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (epi_has_bias(EPI)) b4 = *reinterpret_cast<const f32x4*>(p.bias + min(cb + 16 * nt, p.N - 4));
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t][nt] = b4;
-                }
-            }
-            for (int kt = 0; kt < nk; ++kt) {
-                if (s >= 1) {                                     // the last two stages this group issued in its B phase
-                    if (kt == 0) pp_wait_vm<PP_PER>();
-                    else if (kt == 1) pp_wait_vm<0>();
-                }
-                __syncthreads();
-                const char* st = smem + slot * PP_STAGE_BYTES;
-                slot = slot == 2 ? 0 : slot + 1;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int coff = ((ks * 4 + f_kc) ^ f_sw) << 4;
-                    bf16x8 wf[8], af[4];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(st + fb_base + t * 2048 + coff);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const bf16x8*>(st + fa_base + t * 2048 + coff);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < 8; ++nt)
-                            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[t], acc[t][nt], 0, 0, 0);
-                }
-            }
-        } else {
-            // ================= B phase: loads of slot s, epilogue of tile s - 1 =================
-            const bool has_epi = s >= 1, has_dma = s < n_my;
-            EpiBuf eo, eo2;
-            if (has_epi) {
-                int m0, n0;
-                tile_coords(s - 1, m0, n0);
-                const int e_row = wm * 64 + e_r, e_col = wn * 128 + e_j * 8;
-                eo = epi_buf(p.out, p.ldo, 2, p.M, p.N, m0, n0, e_row, e_col, true);
-                eo2 = eo;
-                if constexpr (EPI == CE_EPI_BIAS_GELU) eo2 = epi_buf(p.out2, p.ldo2, 2, p.M, p.N, m0, n0, e_row, e_col, true);
-            }
-            // one epilogue unit: 16 rows (block t) x 64 columns (half h) of this wave's 64 x 128 block
-            auto unit = [&](auto uc) __attribute__((always_inline)) {
-                constexpr int u = decltype(uc)::value;
-                constexpr int t = u >> 1, h = u & 1;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    *reinterpret_cast<f32x4*>(ebuf + pw_row * 256 + (((nt * 4 + pw_g) ^ pw_row) << 4)) = acc[t][h * 4 + nt];
-#pragma unroll
-                for (int it2 = 0; it2 < 2; ++it2) {
-                    const int row = it2 * 8 + e_r;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ebuf + row * 256 + (((2 * e_j) ^ row) << 4));
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ebuf + row * 256 + (((2 * e_j + 1) ^ row) << 4));
-                    const int es = t * 2 + it2;                   // 8-row slot of the wave's row block
-                    if constexpr (EPI == CE_EPI_BIAS_GELU) {
-                        float gv[8], dv[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            quick_gelu_both(v0[e], gv[e], dv[e]);
-                            quick_gelu_both(v1[e], gv[4 + e], dv[4 + e]);
-                        }
-                        const u32x4 o = {pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3]), pack_bf2(dv[4], dv[5]), pack_bf2(dv[6], dv[7])};
-                        const u32x4 g = {pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3]), pack_bf2(gv[4], gv[5]), pack_bf2(gv[6], gv[7])};
-                        epi_bstore16(eo, es, o, h * 128);
-                        epi_bstore16(eo2, es, g, h * 128);
-                    } else {
-                        const u32x4 o = {pack_bf2(v0[0], v0[1]), pack_bf2(v0[2], v0[3]), pack_bf2(v1[0], v1[1]), pack_bf2(v1[2], v1[3])};
-                        epi_bstore16(eo, es, o, h * 128);
-                    }
-                }
-            };
-            auto units_of = [&](int k) __attribute__((always_inline)) {     // the U units of B-phase iteration k (k < NUI); ONE copy of each unit's code
-                // (the trip count is kept opaque -- tile_strip is 0 for this kernel -- so that the loop survives at U = 1: with the switch
-                //  inlined straight into the iteration loop the compiler hoisted address arithmetic of all eight units and spilled)
-#pragma unroll 1
-                for (int q = 0; q < U + p.tile_strip; ++q) {
-                    switch (k * U + q) {
-                        case 0: unit(std::integral_constant<int, 0>{}); break;
-                        case 1: unit(std::integral_constant<int, 1>{}); break;
-                        case 2: unit(std::integral_constant<int, 2>{}); break;
-                        case 3: unit(std::integral_constant<int, 3>{}); break;
-                        case 4: unit(std::integral_constant<int, 4>{}); break;
-                        case 5: unit(std::integral_constant<int, 5>{}); break;
-                        case 6: unit(std::integral_constant<int, 6>{}); break;
-                        default: unit(std::integral_constant<int, 7>{}); break;
-                    }
-                }
-            };
-            if (has_dma) {
-                if (s + 1 < n_my) desc(s + 1, rA2, rB2);
-                if (s >= 1) desc(s, rA, rB);                      // (s = 0: set by the prologue)
-            }
-            // (the workgroup's last epilogue, !has_dma: nobody multiplies meanwhile -- no waits, no barriers, no loads)
-            for (int kt = 0; kt < (has_dma ? nk : NUI); ++kt) {
-                if (has_dma) {
-                    // this wave's part of stage it = s nk + kt has landed (it issued it two iterations ago; kt < 2: the other group did)
-                    if (kt >= 2 || s == 0) {
-                        const bool last_issued = s * nk + kt + 1 >= total;   // stage it + 1 does not exist: nothing younger than stage it but stores
-                        if (last_issued) pp_wait_vm<0>();
-                        else if (!has_epi || kt >= NUI + 2) pp_wait_vm<PP_PER>();
-                        else if (kt == NUI + 1) pp_wait_vm<PP_PER + U * SO>();
-                        else pp_wait_vm<PP_PER + 2 * U * SO>();
-                    }
-                    __syncthreads();
-                    const int s2 = slot == 0 ? 2 : slot - 1;      // slot of stage it - 1 (read by every wave before this barrier) takes stage it + 2
-                    slot = slot == 2 ? 0 : slot + 1;
-                    if (s * nk + kt + 2 < total) {
-                        if (kt + 2 < nk) issue(rA, rB, s2, kt + 2);
-                        else issue(rA2, rB2, s2, kt + 2 - nk);
-                    }
-                }
-                if (has_epi && kt < NUI) units_of(kt);
-            }
-            if (!has_dma) break;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // NT kernel, 160x256x32 tile, 8 waves, SMALL footprint: 2 x 26 KiB LDS stages and <= 128 VGPRs, so two
 // (even three) workgroups share a CU and one workgroup's epilogue / prologue overlaps another's MFMA loop.
 // Used for the GEMMs that need several rounds of tiles (N = 3d, 4d); per-tile prologue+epilogue is ~40 % of
@@ -2157,33 +1933,6 @@ void launch_nt256(NTArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_nt256_kernel<EPI, TM, 4>), dim3(a.tiles_m * a.tiles_n), dim3(512), N2_LDS_BYTES, stream, a);
 }
 
-// The ping-pong kernel (gemm_nt128pp_kernel) for the shapes it takes; false = not taken.
-template <int EPI>
-bool launch_nt_pp(NTArgs a, hipStream_t stream) {
-    if constexpr (EPI == CE_EPI_BF16 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_GELU) {
-        static std::once_flag attr_set;
-        std::call_once(attr_set, [] {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128pp_kernel<EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128pp_kernel<EPI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128pp_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        });
-        if (a.N % PP_BN != 0 || a.K % 64 != 0 || a.K < 256) return false;
-        const int nk = a.K / 64;
-        a.tiles_m = ce_div_up(a.M, PP_BM);
-        a.tiles_n = a.N / PP_BN;
-        a.tile_strip = 0;
-        a.tile_chunk = 0;
-        const long tiles = (long)a.tiles_m * a.tiles_n;
-        const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(512);
-        if (nk >= 10) hipLaunchKernelGGL((gemm_nt128pp_kernel<EPI, 1>), grid, block, PP_LDS_BYTES, stream, a);
-        else if (nk >= 6) hipLaunchKernelGGL((gemm_nt128pp_kernel<EPI, 2>), grid, block, PP_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((gemm_nt128pp_kernel<EPI, 4>), grid, block, PP_LDS_BYTES, stream, a);
-        return true;
-    } else {
-        return false;
-    }
-}
-
 template <int EPI>
 int launch_nt(NTArgs a, hipStream_t stream) {
     static std::once_flag attr_set;
@@ -2255,25 +2004,10 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         constexpr bool light_epi = EPI == CE_EPI_BF16 || EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BIAS_F32;
         const bool pers = !lw && fits31 && a.K >= 2 * N4_BK && ((f >= 163 && f <= 165) || f == 162 ||
                                                      (f == 0 && !half && ((policy & 32) && light_epi || (policy & 64))));
-        // the ping-pong kernel for the forward's multi-round launches: OFF by default (CE_NT_PP=1 / variant 170 turn it on).
-        // (Second version tried: ONE B wave issues all 48 LDS-DMAs of a stage, the duty rotating, so the other three have the
-        //  iteration for their epilogue unit -- SLOWER, BIAS_GELU 68.0 us, qkv 49.5: an LDS-DMA instruction costs its issuer ~55
-        //  cycles whether or not other waves queue on the path, so 48 of them are 2.6 k cycles on one wave against 660 on each of
-        //  four.  That version also ran units in a period's last iteration and so needed a barrier in front of the workgroup's
-        //  final, barrier-free epilogue -- the other group's last unit was still on the shared transposition tile.)
-        // First version, same box, B = 256 step: BIAS_GELU 63.1 vs 55.4 us per launch, BIAS_BF16 (qkv) 41.0 vs 35.3, step 12.77 vs
-        // 12.40 ms.  Per K iteration it runs 1500 cycles (plain epilogue; A-phase bound: a lone wave per SIMD exposes the fragment
-        // reads' latency after every barrier -- the 64 MFMAs alone are 1024) and 1840 (GELU; B-phase bound: 12 DMA issues ~660
-        // cycles + one 16 x 64 GELU unit ~1100) against 1366 + a 5-10 k cycle epilogue per tile for the kernel below; it needs a
-        // software-pipelined fragment stream in the A phase and the B waves' DMA / epilogue order staggered before it pays.
-        static const int pp_env = getenv("CE_NT_PP") ? atoi(getenv("CE_NT_PP")) : 0;
-        if (fits31 && (f == 170 || (f == 0 && pp_env && pers && (long)ce_div_up(a.M, PP_BM) * (a.N / PP_BN) > 256))) {
-            prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 6);
-            if (launch_nt_pp<EPI>(a, stream)) {
-                CE_LAUNCH_CHECK();
-                return 0;
-            }
-        }
+        // (A two-group "ping-pong" persistent kernel -- 128x256x64 tiles, one group of four waves multiplying while the other
+        //  issues the ring's LDS-DMAs and works through the previous tile's epilogue -- was built, parity-tested and measured in
+        //  round 3: BIAS_GELU 63.1 vs 55.4 us per launch, qkv 41.0 vs 35.3, step 12.77 vs 12.40 ms, slower in both versions; it
+        //  was removed in round 4.  DESIGN 6b keeps the post-mortem.)
         if (pers) {
             // tile height by the longest per-CU tile list: rows of tile work + ~48 rows' worth of epilogue per tile
             int ptm = 5;

@@ -24,6 +24,10 @@ namespace {
 // dY buffers) of the queued blocks stay alive in a ring of WG_SETS buffer sets.
 constexpr int WG_MAX_BLOCKS = 8;            // blocks per grouped launch (x 4 problems <= CE_TN_MAX_GROUP)
 constexpr int WG_SETS = WG_MAX_BLOCKS + 1;  // a block writes its own set and the next block's dxb
+// LayerNorm-backward partial sums: a ring of LNP_RING buffer sets (two per block); ce_layernorm_fold runs whenever the ring is
+// full and at the end of a backward call, so a tower workspace carries 8 sets, not one per layer (ViT-L: 24) -- they only live
+// between a LayerNorm backward and the next fold on the same stream.
+constexpr int LNP_RING = 8;
 
 struct Carver {
     char* base;
@@ -57,7 +61,7 @@ struct Layout {
     // compact [batch, .] buffers of the pruned last block (xs_in / xs_mid / dxs_mid hold stream-typed data)
     float *xs_in, *xs_mid, *dxs_mid, *means, *rstds;
     bf16_t *os, *h2s, *as, *gs, *dxbs, *dxb2s, *das, *dhs, *dos;
-    float* lnp[MAX_LAYERS][2];      // backward: per-workgroup partial sums of the two LayerNorm backwards of a block ([blocks][3][width], ce_layernorm_fold)
+    float* lnp[LNP_RING][2];        // backward: per-workgroup partial sums of the two LayerNorm backwards of a block ([blocks][3][width], ce_layernorm_fold), ring slot l % LNP_RING
     size_t bytes;
 };
 
@@ -99,9 +103,9 @@ void carve(const ce_tower_desc* d, int batch, size_t rows, void* ws, Layout& L) 
     L.dxbs = c.take<bf16_t>(Bn * w); L.dxb2s = c.take<bf16_t>(Bn * w); L.das = c.take<bf16_t>(Bn * 4 * w);
     L.dhs = c.take<bf16_t>(Bn * w); L.dos = c.take<bf16_t>(Bn * w);
     const size_t lnp_floats = (size_t)ce_layernorm_bwd_blocks((int)M, (int)w) * 3 * w;
-    for (int l = 0; l < d->layers; ++l) {
-        L.lnp[l][0] = c.take<float>(lnp_floats);
-        L.lnp[l][1] = c.take<float>(lnp_floats);
+    for (int l = 0; l < LNP_RING; ++l) {
+        L.lnp[l][0] = l < d->layers ? c.take<float>(lnp_floats) : nullptr;
+        L.lnp[l][1] = l < d->layers ? c.take<float>(lnp_floats) : nullptr;
     }
     L.bytes = (c.off + 255) & ~size_t(255);
 }
@@ -246,8 +250,9 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
     // carry instead of adding them atomically (every workgroup of a launch adds into the same rows: 3.7 us of a 23 us launch);
     // one ce_layernorm_fold at the end of the call adds them into the gradients.  CE_LN_FOLD=0: the atomic form.
     static const int ln_fold = getenv("CE_LN_FOLD") ? atoi(getenv("CE_LN_FOLD")) : 1;
-    ce_ln_fold_job fold_jobs[2 * Layout::MAX_LAYERS];
+    ce_ln_fold_job fold_jobs[2 * LNP_RING];
     int n_fold = 0;
+    int fold_rc = 0;
     const int ln_blocks = ce_layernorm_bwd_blocks(M, w);
     auto ln_bwd = [&](const void* dy, const void* xin, const float* mean, const float* rstd, const float* gamma, void* dxb, float* dgw, float* dgb,
                       float* dxs, void* q8, float* partial) -> int {
@@ -255,8 +260,14 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
             return ce_layernorm_bwd_q8(dy, CE_T_BF16, w, xin, ST, w, nullptr, mean, rstd, gamma, dx, ST, dx, ST, w, dxb, w, dgw, dgb, dxs, GS, M, w, q8, w,
                                        L.q8s, stream);
         fold_jobs[n_fold++] = ce_ln_fold_job{partial, dgw, dgb, dxs, ln_blocks, w};
-        return ce_layernorm_bwd_partials(dy, CE_T_BF16, w, xin, ST, w, nullptr, mean, rstd, gamma, dx, ST, dx, ST, w, dxb, w, dxs ? 1 : 0, GS, M, w, q8, w,
-                                         L.q8s, partial, stream);
+        const int rc = ce_layernorm_bwd_partials(dy, CE_T_BF16, w, xin, ST, w, nullptr, mean, rstd, gamma, dx, ST, dx, ST, w, dxb, w, dxs ? 1 : 0, GS, M, w, q8, w,
+                                                 L.q8s, partial, stream);
+        if (rc == 0 && n_fold == 2 * LNP_RING) {               // ring full: fold now, the slots are free again (same stream)
+            fold_rc = ce_layernorm_fold(fold_jobs, n_fold, stream);
+            n_fold = 0;
+            return fold_rc;
+        }
+        return rc;
     };
     // Where to cut the block sequence into grouped launches.  A launch of T unsplit 256x256 tiles takes ceil(T / 256)
     // rounds of the 256 CUs and every round costs a full tile time, so the cuts are chosen (small dynamic programme over
@@ -375,7 +386,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         TRY(linear(b8, L, q8_of, da, 4 * w, p.wt_fc, p.wt8_fc, p.st8_fc, M, w, 4 * w, CE_EPI_BF16, nullptr, nullptr, 0, L.dh, w, nullptr, 0,
                        nullptr, 0, stream));                                      // dh2 = da Wf
         // ---- ln_2 (+ residual); also the column sums of dx = attn.out_proj bias gradient ----
-        TRY(ln_bwd(L.dh, s.x_mid, s.mean2, s.rstd2, p.ln2_w, dxb_b, p.g_ln2_w, p.g_ln2_b, p.g_b_out, lnq ? L.q8 : nullptr, L.lnp[l][1]));
+        TRY(ln_bwd(L.dh, s.x_mid, s.mean2, s.rstd2, p.ln2_w, dxb_b, p.g_ln2_w, p.g_ln2_b, p.g_b_out, lnq ? L.q8 : nullptr, L.lnp[l % LNP_RING][1]));
         if (lnq) q8_of = dxb_b;
         // ---- attn.out_proj : x_mid = x_in + o Wo^T + bo ----
         TRY(linear(b8, L, q8_of, dxb_b, w, p.wt_out, p.wt8_out, p.st8_out, M, w, w, CE_EPI_BF16, nullptr, nullptr, 0, L.d_o, w, nullptr, 0, nullptr, 0,
@@ -396,7 +407,7 @@ extern "C" int ce_tower_backward_range(const ce_tower_desc* d, int batch, int ro
         // ---- ln_1 (+ residual); column sums of dx = previous block's mlp.c_proj bias gradient.  It writes the
         // next block's dxb (set l-1) ----
         TRY(ln_bwd(L.dh, x_in, s.mean1, s.rstd1, p.ln1_w, L.dxb[(l + WG_SETS - 1) % WG_SETS], p.g_ln1_w, p.g_ln1_b,
-                   (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, (lnq && l > layer_lo) ? L.q8 : nullptr, L.lnp[l][0]));
+                   (l > 0) ? d->blocks[l - 1].g_b_proj : nullptr, (lnq && l > layer_lo) ? L.q8 : nullptr, L.lnp[l % LNP_RING][0]));
         if (lnq && l > layer_lo) q8_of = L.dxb[(l + WG_SETS - 1) % WG_SETS];     // consumed by the next block's GELU' GEMM in THIS call
     }
     // the caller hands the gradients of blocks >= layer_lo to the all-reduce as soon as this returns: nothing stays queued

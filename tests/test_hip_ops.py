@@ -140,16 +140,14 @@ def test_gemm_nt_persistent_xcd_owned_walk(M, N, K):
             lib.ce_gemm_nt_tune(1001)
 
 
-@pytest.mark.parametrize("M,N,K,forced", [(12800, 3072, 768, False), (12800, 2304, 768, False), (11137, 2048, 512, False),
-                                          (9000, 1536, 256, True), (3000, 512, 256, True), (300, 256, 1024, True),
-                                          (33000, 768, 384, False), (2 * 128 * 86 + 5, 768, 640, False)])
-def test_gemm_nt_ping_pong_kernel(M, N, K, forced):
-    """The ping-pong persistent kernel (gemm_nt128pp_kernel: two wave groups half a tile period apart, hand-counted vmcnt around the
-    epilogue stores) against the fp32 product of the same bf16 operands, for its three epilogues: the towers' forward shapes (one
-    epilogue unit per iteration at K = 768, two at K = 512), four units per iteration (K = 256: the shortest contraction it
-    takes), workgroups with one tile only / a single tile in the launch, odd and even tile counts per workgroup with a ragged last
-    row panel, K not a multiple of 128.  Every output element must be written exactly once and nothing else.  The kernel is opt-in
-    (variant 170 / CE_NT_PP=1); `forced` marks the shapes the size policy would not route to a persistent kernel at all."""
+@pytest.mark.parametrize("M,N,K", [(12800, 3072, 768), (12800, 768, 768), (11137, 2048, 512), (10807, 512, 2048),
+                                   (9000, 1536, 256), (3000, 512, 256), (33000, 768, 384), (2 * 128 * 86 + 5, 768, 640)])
+@pytest.mark.parametrize("cus", [224, 97])
+def test_gemm_nt_under_a_cu_budget(M, N, K, cus):
+    """``ce_gemm_set_cu_budget``: the NT launch policies sized for fewer CUs than the chip has (what is left while RCCL's
+    channel kernels hold some) -- one-round launches re-tiled or moved to the persistent kernel, persistent grids
+    of ``cus`` workgroups with longer tile lists, ragged last panels -- against the fp32 product of the same bf16 operands.
+    Every output element written exactly once, guard rows untouched; the budget is restored afterwards."""
     from clip_event_amd import ops, _lib as L
     rng = np.random.default_rng(M + N + K)
     a = _randn(rng, M, K).to(torch.bfloat16)
@@ -158,24 +156,25 @@ def test_gemm_nt_ping_pong_kernel(M, N, K, forced):
     A, B = a.to(DEV), b.to(DEV)
     acc = (A.float() @ B.float().t()).cpu()
     lib = L.lib()
-    lib.ce_gemm_nt_tune(170)          # the kernel is opt-in (CE_NT_PP=1 / variant 170)
+    assert lib.ce_gemm_set_cu_budget(cus) == 0
     try:
         guard = torch.full((M + 64, N), 7.0, device=DEV, dtype=torch.bfloat16)      # rows past M must stay untouched
         out = guard[:M]
         ops.gemm_nt(A, B, L.EPI_BF16, out=out)
         torch.cuda.synchronize()
-        assert torch.equal(out.cpu(), acc.to(torch.bfloat16)) or _report("pp bf16", out.float().cpu(), acc.to(torch.bfloat16).float())[1] < 1e-3
+        assert torch.equal(out.cpu(), acc.to(torch.bfloat16)) or _report("budget bf16", out.float().cpu(), acc.to(torch.bfloat16).float())[1] < 1e-3
         assert bool((guard[M:] == 7.0).all())
         o = ops.gemm_nt(A, B, L.EPI_BIAS_BF16, bias=bias.to(DEV)).float().cpu()
-        assert _report("pp bias_bf16", o, (acc + bias).to(torch.bfloat16).float())[1] < 3e-3
+        assert _report("budget bias_bf16", o, (acc + bias).to(torch.bfloat16).float())[1] < 3e-3
         dact, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
         h = acc + bias
         sg = torch.sigmoid(1.702 * h)
-        assert _report("pp gelu derivative", dact.float().cpu(), sg * (1 + 1.702 * h * (1 - sg)))[1] < 3e-3
-        assert _report("pp gelu act", g.float().cpu(), h * sg)[1] < 3e-3
+        assert _report("budget gelu derivative", dact.float().cpu(), sg * (1 + 1.702 * h * (1 - sg)))[1] < 3e-3
+        assert _report("budget gelu act", g.float().cpu(), h * sg)[1] < 3e-3
         assert torch.isfinite(g.float()).all() and torch.isfinite(dact.float()).all()
     finally:
-        lib.ce_gemm_nt_tune(0)
+        assert lib.ce_gemm_set_cu_budget(0) == 0
+    assert lib.ce_gemm_set_cu_budget(7) != 0          # out of range: refused, budget unchanged
 
 
 TN_SHAPES = [(64, 128, 128), (256, 256, 384), (1000, 768, 512), (77 * 8, 512, 2048), (50, 64, 72), (12800, 768, 768),
