@@ -236,3 +236,80 @@ def test_persistent_gemm_tile_walk_is_a_bijection():
             for tm, _, xcd in seen:
                 owners.setdefault(tm, set()).add(xcd)
             assert max(len(v) for v in owners.values()) <= 2, (tiles_m, tiles_n)
+
+
+def test_caption_lengths_travel_on_the_host():
+    """Round 4: the text tower sizes its launches from HOST-side caption lengths (no device read-back): ``clip.tokenize``
+    tags its result, ``tokens_to_device`` / ``attach_lengths`` / ``host_lengths`` agree with argmax + 1 (first occurrence of
+    the row maximum, model_clip.py:415), and the packed-layout metadata built from them is what the device path would build."""
+    import numpy as np
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.clip import tokenize
+    from clip_event_amd.functional import attach_lengths, host_lengths, tokens_to_device
+    t = tokenize(["a photo of a cat", "hello", ""])
+    assert np.array_equal(t._ce_lengths, (t.argmax(dim=-1) + 1).numpy())
+    assert t._ce_lengths.tolist()[-1] == 2                      # the empty caption: SOT EOT
+    txt = S.synthetic_tokens(37, 77, 49408, seed=3, min_len=1)
+    lens = host_lengths(txt)
+    assert np.array_equal(lens, (txt.argmax(dim=-1) + 1).numpy())
+    same = tokens_to_device(txt, "cpu")                         # already "there": returned as is (is_cuda False -> a copy with the tag)
+    assert np.array_equal(getattr(same, "_ce_lengths"), lens)
+    v = attach_lengths(txt.clone(), lens.tolist())
+    assert v._ce_lengths.dtype == np.int64 and v._ce_lengths.shape == (37,)
+    # a 3-D entity tensor: lengths are per row of the flattened [B * M, T] view
+    ent = txt[:36].reshape(6, 6, 77)
+    assert np.array_equal(host_lengths(ent), lens[:36])
+
+
+def test_region_plan_keeps_the_reference_quirks():
+    """``region.region_plan`` (the tower-free half of model_clip.py:430-455) against the oracle's loop: which boxes are pooled,
+    which images are dropped (no usable box, or the LAST box None), the x / y transposition of the slice, the order of the
+    role rows."""
+    import torch
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.region import region_plan
+    from oracle import clip_oracle as O
+
+    class _V:
+        patch_num = 7
+
+    class _M:
+        visual = _V()
+
+    boxes = S.synthetic_bboxes(24, seed=5, max_roles=4, none_frac=0.4)
+    boxes[3] = [None, None]                       # nothing usable
+    boxes[4] = [(0.1, 0.2, 0.5, 0.9), None]       # last box None: dropped although one box is usable
+    boxes[5] = [None, (0.0, 0.0, 1.0, 1.0)]
+    desc = S.synthetic_role_texts(boxes, seed=6)
+    lab = S.synthetic_role_texts(boxes, seed=7)
+    plan = region_plan(_M(), boxes, desc, lab, "desc_type_text", torch.device("cpu"))
+    want_boxes, want_rows, want_groups = [], [], []
+    for i, bx in enumerate(boxes):
+        use = [(j, b) for j, b in enumerate(bx) if b is not None]
+        if not use or bx[-1] is None:
+            continue
+        want_groups.append(len(use))
+        for j, b in use:
+            x0, y0, x1, y1 = O.patch_from_norm_bbox(b, 7)
+            want_boxes.append([i, x0, y0, x1, y1])
+            want_rows.append(desc[i][j])
+    assert plan.boxes.tolist() == want_boxes
+    assert torch.equal(plan.descs, torch.stack(want_rows))
+    off = plan.offsets.tolist()
+    assert [off[k + 1] - off[k] for k in range(len(off) - 1)] == want_groups and plan.groups == len(want_groups)
+    assert plan.use_label and plan.use_role_text and plan.labs.shape == plan.descs.shape
+    assert (plan.descs._ce_lengths == (plan.descs.argmax(dim=-1) + 1).numpy()).all()
+    assert region_plan(_M(), [[None]], [desc[0][:1]], [lab[0][:1]], "desc", torch.device("cpu")) is None
+
+
+def test_visible_gpus_counts_without_hip(monkeypatch):
+    from clip_event_amd.launch import visible_gpus
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    n = visible_gpus()
+    assert n is None or n >= 0
