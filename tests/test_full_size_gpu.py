@@ -221,8 +221,15 @@ def test_full_size_fp16_stream_step(vitb32):
           f"flat gradient rel {_rel(g16, g32):.3e}")
     assert abs(li16 - li32) < 1e-3 and abs(lt16 - lt32) < 1e-3
     # two builds that each sit 3-5e-3 from the same-rounding oracle (bf16 roundings that flip with any upstream change):
-    # 1e-2 between them (measured 3.0e-3 image / 5.5e-3 text)
+    # 1e-2 between them.  Measured (round 3): image 3.0e-3, text 5.5e-3 -- a drift
+    # past 7e-3 is reported as a warning long before the bound trips.  This is a self-comparison; the checks that face the
+    # REFERENCE run the fp16 stream at the fp32 stream's tolerances: test_vitb32_b8_against_reference_golden[stream16] and
+    # test_vitb32_b8_gradient_error_is_at_the_bf16_noise_floor[stream16] (tests/test_model_gpu.py), and, at trained-like
+    # statistics, tests/test_stream16_hostile_gpu.py.
     assert _rel(fi16, fi32) < 1e-2 and _rel(ft16, ft32) < 1e-2
+    if max(_rel(fi16, fi32), _rel(ft16, ft32)) > 7e-3:
+        import warnings
+        warnings.warn(f"fp16-stream vs fp32-stream features drifted: {_rel(fi16, fi32):.2e} / {_rel(ft16, ft32):.2e} (measured 3.0e-3 / 5.5e-3)")
     assert bool(torch.isfinite(g16).all())
     for name, (a, b) in m._ranges.items():
         if b > a and float(g32[a:b].norm()) > 0:
