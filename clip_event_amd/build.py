@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             continue
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("CE_EXTRA_FLAGS", "").split(), "-x", "hip", "-c", src, "-o", obj]     # (diagnostic builds: -DCE_... switches)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

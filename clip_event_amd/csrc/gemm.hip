@@ -513,7 +513,10 @@ constexpr int N4_BM = 160, N4_BN = 256, N4_BK = 64, N4_TM = 5;
 constexpr int N4_A_BYTES = N4_BM * N4_BK * 2;                // 20 KiB
 constexpr int N4_STAGE_BYTES = (N4_BM + N4_BN) * N4_BK * 2;   // 52 KiB
 constexpr int N4_LDS_BYTES = 3 * N4_STAGE_BYTES;             // 156 KiB (>= 8 epilogue slices of 17 KiB)
-constexpr int N4_LOADERS = 4;                                // loader waves of gemm_nt160lw_kernel (divides 20 and 32)
+#ifndef CE_N4_LOADERS
+#define CE_N4_LOADERS 4
+#endif
+constexpr int N4_LOADERS = CE_N4_LOADERS;                    // loader waves of gemm_nt160lw_kernel (divides 20, 16, 12 and 32: 4 or 2)
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt160_kernel(NTArgs p) {
