@@ -23,6 +23,7 @@
 // global_atomic_add_f32.  The M range is split across workgroups to fill the chip.
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
 #include <type_traits>
 
@@ -513,6 +514,7 @@ constexpr int N4_BM = 160, N4_BN = 256, N4_BK = 64, N4_TM = 5;
 constexpr int N4_A_BYTES = N4_BM * N4_BK * 2;                // 20 KiB
 constexpr int N4_STAGE_BYTES = (N4_BM + N4_BN) * N4_BK * 2;   // 52 KiB
 constexpr int N4_LDS_BYTES = 3 * N4_STAGE_BYTES;             // 156 KiB (>= 8 epilogue slices of 17 KiB)
+constexpr int N4P_LDS_BYTES = N4_LDS_BYTES + 64;             // persistent kernel: + the two tile ids of its dynamic tile list
 #ifndef CE_N4_LOADERS
 #define CE_N4_LOADERS 4
 #endif
@@ -943,11 +945,17 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const PersistWalk walk = persist_walk(p, p.tiles_m * p.tiles_n);   // this workgroup's tiles: first + t * step (grid <= tiles)
-    const int n_my = walk.count;
+    const int total = p.tiles_m * p.tiles_n;
+    const PersistWalk walk = persist_walk(p, total);              // this workgroup's tiles: first + t * step (grid <= tiles)
     constexpr int ES = F8 ? 1 : 2;                                // bytes per operand element; a stage is 128 bytes of every row
     const int nk = p.K * ES / 128;                                // >= 2
     const uint32_t lds0 = (uint32_t)(size_t)(lptr_t*)smem;
+    // DYNAMIC tile list (p.tile_queue; the launcher sets it only for nk >= 3 and the launch-wide walk): the first tile is the
+    // static one, every further tile is fetched from a device counter by compute wave 0 while the current tile runs.  A workgroup
+    // that the dispatcher could not place (its CU held by another stream's kernel: an RCCL channel) then finds the
+    // list empty when it finally starts, instead of holding the launch up for a whole static list.
+    const bool dyn = p.tile_queue != nullptr;
+    volatile int* tq = reinterpret_cast<volatile int*>(smem + 3 * N4_STAGE_BYTES);      // [2]: id of tile t in tq[t & 1] (behind the ring)
 
     if (wave >= 8) {
         // ---- loader waves: instruction j = lw + N4_LOADERS * i of a stage (8 rows x 128 B each; A_INSTR of A, then 32 of B)
@@ -957,9 +965,9 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
         const uint32_t vA0 = (uint32_t)((lw * 8 + s_row) * p.lda * ES + s_chunk * 16);
         const uint32_t vB0 = (uint32_t)((lw * 8 + s_row) * p.ldb * ES + s_chunk * 16);
         const uint32_t stepA = (uint32_t)(8 * N4_LOADERS * p.lda * ES), stepB = (uint32_t)(8 * N4_LOADERS * p.ldb * ES);
-        auto desc = [&](int t, u32x4& rA, u32x4& rB) {
+        auto desc_tile = [&](int tile, u32x4& rA, u32x4& rB) {
             int tm, tn;
-            persist_coords(p, walk.first + t * walk.step, tm, tn);
+            persist_coords(p, tile, tm, tn);
             const int m0 = tm * BM, n0 = tn * N4_BN;
             rA = make_rsrc_words(reinterpret_cast<const char*>(p.A) + (long)m0 * p.lda * ES, (uint32_t)((long)min(p.M - m0, BM) * p.lda * ES));
             rB = make_rsrc_words(reinterpret_cast<const char*>(p.B) + (long)n0 * p.ldb * ES, (uint32_t)((long)min(p.N - n0, N4_BN) * p.ldb * ES));
@@ -973,19 +981,28 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
             for (int i = 0; i < 32 / N4_LOADERS; ++i) dma16_bounds(rB, base + A_BYTES + i * (1024 * N4_LOADERS), vB0 + i * stepB + kb);
         };
         u32x4 rA, rB, rA2, rB2;
-        desc(0, rA, rB);
+        desc_tile(walk.first, rA, rB);
         rA2 = rA; rB2 = rB;
         issue(rA, rB, 0, 0);
         issue(rA, rB, 1, 1);
         int slot = 0;                                             // ring slot of the stage the compute waves multiply next
-        for (int t = 0; t < n_my; ++t) {
-            const bool has_next = t + 1 < n_my;
-            if (has_next) desc(t + 1, rA2, rB2);
+        int cur = walk.first;
+        for (int t = 0; cur < total; ++t) {
+            // the next tile: static list (first + (t + 1) step), or -- dynamic -- the id compute wave 0 fetched during this tile's
+            // first K iteration and parked in tq[(t + 1) & 1] (published by the barrier of iteration 1; nk >= 3)
+            int nxt = dyn ? total : cur + walk.step;
+            bool has_next = !dyn && nxt < total;
+            if (has_next) desc_tile(nxt, rA2, rB2);
             for (int kt = 0; kt < nk; ++kt) {
                 // this wave's part of stage (t, kt) has landed; the following stage (issued already) may be in flight
                 if (kt + 1 < nk || has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                                  // publishes the stage; the previous one has been read
+                if (dyn && kt == nk - 2) {
+                    nxt = __builtin_amdgcn_readfirstlane(tq[(t + 1) & 1]);
+                    has_next = nxt < total;
+                    if (has_next) desc_tile(nxt, rA2, rB2);
+                }
                 const int s2 = slot == 0 ? 2 : slot - 1;          // its slot takes the stage two ahead
                 if (kt + 2 < nk) issue(rA, rB, s2, kt + 2);
                 else if (has_next) issue(rA2, rB2, s2, kt + 2 - nk);
@@ -993,6 +1010,7 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
             }
             __syncthreads();                                      // the tile's last stage has been read: its slot is epilogue scratch
             rA = rA2; rB = rB2;
+            cur = nxt;
         }
         return;
     }
@@ -1004,9 +1022,10 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
     constexpr int EROW = 272;
     const int e_r = lane >> 3, e_c = (lane & 7) * 8;
     int slot = 0;
-    for (int t = 0; t < n_my; ++t) {
+    int cur = walk.first;
+    for (int t = 0; cur < total; ++t) {
         int tm, tn;
-        persist_coords(p, walk.first + t * walk.step, tm, tn);
+        persist_coords(p, cur, tm, tn);
         const int m0 = tm * BM, n0 = tn * N4_BN;
         f32x4 acc[TM][4];
 #pragma unroll
@@ -1021,7 +1040,16 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
             slot = slot == 2 ? 0 : slot + 1;
             nt160_stage_mma<TM, F8>(st, fa_base, fb_base, f_kc, f_sw, acc);
         };
-        for (int kt = 0; kt + 1 < nk; ++kt) k_iter();
+        // dynamic list: wave 0 requests the next tile id now (one returning atomic from lane 0; the other lanes' offsets are
+        // out of the descriptor's range) and parks it in LDS after the first K iteration, where its latency has passed
+        int fetched = 0;
+        if (dyn && wave == 0) {
+            const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.tile_queue, 4u);
+            fetched = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rq, lane == 0 ? 0 : 64, 0, 0);
+        }
+        k_iter();
+        if (dyn && wave == 0 && lane == 0) tq[(t + 1) & 1] = (int)gridDim.x + fetched;
+        for (int kt = 1; kt + 1 < nk; ++kt) k_iter();
         // Epilogue I/O through per-tile buffer descriptors, branch-free (EpiBuf, gemm_common.hpp); the bias / column scales on a
         // clamped column.
         const int gn = n0 + wn * 64 + e_c;
@@ -1133,6 +1161,8 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
                 if (gn + e < p.N) atomicAdd(colsum + gn + e, v);
             }
         }
+        // next tile: the static list, or the id wave 0 parked during this tile (every wave has passed a barrier since)
+        cur = dyn ? __builtin_amdgcn_readfirstlane(tq[(t + 1) & 1]) : cur + walk.step;
     }
 }
 
@@ -1900,6 +1930,28 @@ int force_tm() {   // CE_GEMM_TM / ce_gemm_nt_tune(): 3..8 = tile height (x32 ro
 // K = 512, scales with K): one round of 32*TM-row tiles on the 256 CUs costs 28 + 10*TM (the K loop is
 // LDS-read bound: a fixed share for the 256-column B fragments plus TM A fragments per k-step); the
 // 160x256x32 kernel keeps two workgroups per CU: a co-resident pair costs 146, a lone one 78.
+// Tile queues of the persistent kernel's DYNAMIC tile list (NTArgs.tile_queue): one zero-initialised counter per launch, taken from a
+// ring per stream; the ring is re-zeroed on its stream when it wraps, behind every launch that used it.  CE_NT_DYNAMIC = 1 (or
+// ce_gemm_set_dynamic_tiles) turns the dynamic list on for persistent launches with >= 3 K iterations on the launch-wide walk.
+struct TileQueueRing { unsigned int* dev = nullptr; int next = 0; };
+constexpr int TQ_RING = 1024;
+std::mutex g_tq_mu;
+std::map<hipStream_t, TileQueueRing> g_tq;
+int g_dynamic = getenv("CE_NT_DYNAMIC") ? atoi(getenv("CE_NT_DYNAMIC")) : 0;
+unsigned int* next_tile_queue(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_tq_mu);
+    TileQueueRing& r = g_tq[s];
+    if (!r.dev) {
+        if (hipMalloc(&r.dev, TQ_RING * sizeof(unsigned int)) != hipSuccess) return nullptr;
+        r.next = TQ_RING;
+    }
+    if (r.next >= TQ_RING) {
+        if (hipMemsetAsync(r.dev, 0, TQ_RING * sizeof(unsigned int), s) != hipSuccess) return nullptr;
+        r.next = 0;
+    }
+    return r.dev + r.next++;
+}
+
 // CU budget of the NT launch policies (ce_gemm_set_cu_budget / CE_GEMM_CUS, default 256 = the whole chip).  Every NT kernel here
 // puts ONE 156 KiB workgroup on a CU and sizes its grid to fill the chip exactly once (one-round launches: 226-240 tiles;
 // persistent launches: 256 workgroups), so a single CU held by another stream's kernel -- an RCCL channel during a gradient
@@ -1955,11 +2007,11 @@ int launch_nt(NTArgs a, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
     });
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_RESID_F16 ? 4.0 : 2.0));
     CeProfScope prof(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
@@ -2041,11 +2093,14 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             static const int pgrid_env = getenv("CE_NT_PGRID") ? atoi(getenv("CE_NT_PGRID")) : 0;
             const int pgrid = pgrid_env > 0 ? pgrid_env : cu_budget();
             const dim3 grid((unsigned)(tiles < pgrid ? tiles : pgrid)), block(64 * (8 + N4_LOADERS));
+            // dynamic tile list (off by default): only where a workgroup walks more than one tile, with >= 3 K iterations
+            // (the fetched id is published by the barrier of iteration 1 and needed from iteration nk - 2) on the launch-wide walk
+            a.tile_queue = (g_dynamic && tiles > (long)grid.x && a.K >= 3 * N4_BK && a.tile_chunk == 0) ? next_tile_queue(stream) : nullptr;
             prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 6);
             switch (ptm) {
-                case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3>), grid, block, N4_LDS_BYTES, stream, a); break;
-                case 4: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4>), grid, block, N4_LDS_BYTES, stream, a); break;
-                default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5>), grid, block, N4_LDS_BYTES, stream, a); break;
+                case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3>), grid, block, N4P_LDS_BYTES, stream, a); break;
+                case 4: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4>), grid, block, N4P_LDS_BYTES, stream, a); break;
+                default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5>), grid, block, N4P_LDS_BYTES, stream, a); break;
             }
         } else if (lw) {
             // shortest tile whose launch still fits one round of the 256 CUs (the text tower's N = 512 has two tile columns)
@@ -2133,8 +2188,8 @@ int launch_nt_f8(NTArgs a, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
     });
     if (!(a.M >= 1024 && a.N >= 256 && a.K % 128 == 0 && a.K >= 256 && a.N % 8 == 0 && a.lda % 16 == 0 && a.ldb % 16 == 0 &&
           a.ldo % 8 == 0 && a.ldo2 % 8 == 0 && a.ldaux % 8 == 0))
@@ -2172,8 +2227,8 @@ int launch_nt_f8(NTArgs a, hipStream_t stream) {
         const long tiles = (long)a.tiles_m * a.tiles_n;
         const dim3 grid((unsigned)(tiles < cu_budget() ? tiles : cu_budget()));
         switch (ptm) {
-            case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3, 1>), grid, block, N4_LDS_BYTES, stream, a); break;
-            default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1>), grid, block, N4_LDS_BYTES, stream, a); break;
+            case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3, 1>), grid, block, N4P_LDS_BYTES, stream, a); break;
+            default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1>), grid, block, N4P_LDS_BYTES, stream, a); break;
         }
     }
     CE_LAUNCH_CHECK();
@@ -2204,6 +2259,11 @@ extern "C" int ce__gemm_nt_fp8_lw(const void* A8, long lda, const float* sa, con
         case CE_EPI_GELUGRAD_BF16: return launch_nt_f8<CE_EPI_GELUGRAD_BF16>(a, s);
         default: return 1;
     }
+}
+
+extern "C" int ce_gemm_set_dynamic_tiles(int on) {
+    g_dynamic = on < 0 ? (getenv("CE_NT_DYNAMIC") ? atoi(getenv("CE_NT_DYNAMIC")) : 0) : (on != 0);
+    return 0;
 }
 
 extern "C" int ce_gemm_set_cu_budget(int cus) {

@@ -16,6 +16,8 @@ struct NTArgs {
     int tiles_m, tiles_n;
     int tile_strip = 0;          // persistent kernel: tiles are walked in column strips of this many tiles (0: row-major)
     int tile_chunk = 0;          // persistent kernel: > 0 = XCD-owned walk in chunks of this many row panels (persist_walk)
+    unsigned int* tile_queue = nullptr;   // persistent kernel: != null = DYNAMIC tile list -- a workgroup's first tile is its static one,
+                                          // every further tile is grid + atomicAdd(*tile_queue, 1) (zeroed by the launcher)
     const float* sa = nullptr;   // fp8 path: per-row dequantisation scales of A (M) ...
     const float* sb = nullptr;   // ... and of B (N); the epilogue multiplies the accumulator by sa[m] * sb[n]
     const uint8_t* sa8 = nullptr;   // fp8 path, MX form: E8M0 block scales of A [M, K/32] ...

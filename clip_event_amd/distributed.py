@@ -178,6 +178,12 @@ class GradSync:
         self.pending = []
         self._reset()
         model.grad_sync = self            # callable: (model, tower, upto_layer=None); also queried for layer_cuts
+        # With a process group live, RCCL's channel kernels will sit on some CUs while the backward runs: hand the persistent
+        # GEMMs' tiles out dynamically, so that a workgroup the dispatcher could not place does not hold a launch up for a whole
+        # static tile list (15.3 -> 14.9 ms beside an 8-CU "hog", no cost without one).  CE_NT_DYNAMIC overrides.
+        if active() and "CE_NT_DYNAMIC" not in os.environ and model.positional_embedding.is_cuda:
+            from ._lib import lib
+            lib().ce_gemm_set_dynamic_tiles(1)
 
     def _reset(self):
         self.done = set()

@@ -461,6 +461,12 @@ void ce_gemm_nt_fp8_tune(int variant);
  * for that many CUs and leaves the rest to whoever holds them; 0 restores the default (CE_GEMM_CUS, else 256).  Process-wide;
  * call between steps. */
 int ce_gemm_set_cu_budget(int cus);
+/* DYNAMIC tile lists in the persistent NT kernel (off by default; CE_NT_DYNAMIC=1 or this call; -1 = back to the environment's
+ * choice): a workgroup's first tile is its static one, every further tile comes from a per-launch device counter, fetched by
+ * one wave while the current tile is multiplied.  A workgroup the dispatcher could not place -- its CU is held by another
+ * stream's kernel, e.g. an RCCL channel during the gradient all-reduce -- then finds the list empty when it starts instead of
+ * holding the launch up for a whole static tile list (measured: 1.2-1.4x per launch beside a resident foreign workgroup). */
+int ce_gemm_set_dynamic_tiles(int on);
 
 /* "CU hog" (bench.py --cu-hog): `blocks` workgroups that each occupy one CU (96 KiB of LDS, 256 threads) for
  * `microseconds` of wall time and do nothing -- what RCCL's channel kernels take away from the GEMM grids during a gradient

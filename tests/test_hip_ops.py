@@ -177,6 +177,43 @@ def test_gemm_nt_under_a_cu_budget(M, N, K, cus):
     assert lib.ce_gemm_set_cu_budget(7) != 0          # out of range: refused, budget unchanged
 
 
+@pytest.mark.parametrize("M,N,K", [(12800, 3072, 768), (12800, 2304, 768), (11137, 2048, 512), (10807, 1536, 512),
+                                   (9000, 1536, 256), (33000, 768, 384), (2 * 128 * 86 + 5, 768, 640), (5000, 2048, 192)])
+@pytest.mark.parametrize("cus", [0, 61])
+def test_gemm_nt_dynamic_tile_list(M, N, K, cus):
+    """``ce_gemm_set_dynamic_tiles``: the persistent NT kernel with its tiles handed out by a device counter (first tile
+    static, the rest fetched one tile ahead by one wave) -- every output element written exactly once, guard rows untouched,
+    for the towers' multi-round shapes, three to twelve K iterations, ragged last panels, and a 61-workgroup grid where
+    every workgroup walks many tiles; twice in a row on one stream (consecutive launches take consecutive counters of the
+    stream's ring)."""
+    from clip_event_amd import ops, _lib as L
+    rng = np.random.default_rng(M + N + K)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    bias = _randn(rng, N)
+    A, B = a.to(DEV), b.to(DEV)
+    acc = (A.float() @ B.float().t()).cpu()
+    lib = L.lib()
+    assert lib.ce_gemm_set_dynamic_tiles(1) == 0 and lib.ce_gemm_set_cu_budget(cus) == 0
+    lib.ce_gemm_nt_tune(162)                    # the persistent kernel whatever the size policy says
+    try:
+        for rep in range(2):
+            guard = torch.full((M + 64, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            out = guard[:M]
+            ops.gemm_nt(A, B, L.EPI_BF16, out=out)
+            torch.cuda.synchronize()
+            assert torch.equal(out.cpu(), acc.to(torch.bfloat16)) or _report("dynamic bf16", out.float().cpu(), acc.to(torch.bfloat16).float())[1] < 1e-3
+            assert bool((guard[M:] == 7.0).all())
+        dact, g = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=bias.to(DEV))
+        h = acc + bias
+        sg = torch.sigmoid(1.702 * h)
+        assert _report("dynamic gelu derivative", dact.float().cpu(), sg * (1 + 1.702 * h * (1 - sg)))[1] < 3e-3
+        assert _report("dynamic gelu act", g.float().cpu(), h * sg)[1] < 3e-3
+    finally:
+        lib.ce_gemm_nt_tune(0)
+        assert lib.ce_gemm_set_dynamic_tiles(-1) == 0 and lib.ce_gemm_set_cu_budget(0) == 0
+
+
 TN_SHAPES = [(64, 128, 128), (256, 256, 384), (1000, 768, 512), (77 * 8, 512, 2048), (50, 64, 72), (12800, 768, 768),
              (4096, 512, 2048), (2120, 256, 256), (11137, 2048, 512)]      # the last three: the 256x256-tile kernel, ragged M
 
