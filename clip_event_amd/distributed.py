@@ -181,7 +181,9 @@ class GradSync:
         # With a process group live, RCCL's channel kernels will sit on some CUs while the backward runs: hand the persistent
         # GEMMs' tiles out dynamically, so that a workgroup the dispatcher could not place does not hold a launch up for a whole
         # static tile list (15.3 -> 14.9 ms beside an 8-CU "hog", no cost without one).  CE_NT_DYNAMIC overrides.
-        if active() and "CE_NT_DYNAMIC" not in os.environ and model.positional_embedding.is_cuda:
+        flat = getattr(model, "_flat_grad", None)
+        on_gpu = flat.is_cuda if flat is not None else any(p.is_cuda for p in getattr(model, "parameters", lambda: [])())
+        if active() and "CE_NT_DYNAMIC" not in os.environ and on_gpu:
             from ._lib import lib
             lib().ce_gemm_set_dynamic_tiles(1)
 
