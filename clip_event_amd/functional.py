@@ -102,6 +102,12 @@ def tokens_to_device(text: torch.Tensor, device) -> torch.Tensor:
     lens = getattr(text, "_ce_lengths", None)
     if lens is None:
         lens = host_lengths(text)
+    if torch.device(device).type == "cuda" and not text.is_pinned():
+        # a copy from pageable memory blocks the host until the stream has drained (the step could not run ahead any more):
+        # stage it through pinned memory ourselves (tens of KB; the caching host allocator keeps the block until the copy is done)
+        pin = torch.empty(text.shape, dtype=text.dtype, pin_memory=True)
+        pin.copy_(text)
+        text = pin
     out = text.to(device, non_blocking=True)
     out._ce_lengths = lens
     return out

@@ -25,7 +25,8 @@ def batch(rng, B, K, dev):
     imgs = [torch.from_numpy(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).to(dev) for (w, h) in sizes]
     image = preprocess(imgs)                                                    # clip.py:62-69 on the GPU
     texts = [CAPTIONS[int(rng.integers(len(CAPTIONS)))] + f" number {int(rng.integers(1000))}" for _ in range(B * K)]
-    text = clip.tokenize(texts).to(dev)                                         # clip.py:168-201
+    text = clip.tokenize(texts)                                                 # clip.py:168-201: stays on the HOST, as the reference's loader
+                                                                                # yields it -- train_step copies it and keeps the caption lengths
     yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=dev)                 # dataset_voa.py:605-664
     return image, text, yi, yt, ip
 
@@ -65,6 +66,21 @@ def main():
     ld = train_step(model2, criterion, optimizer2, *new)
     scheduler2.step()
     assert all(torch.isfinite(v) for v in ld.values())
+    # a longer stretch of fresh batches with no host synchronisation in the loop: host-side caption lengths, the run-ahead
+    # limit of engine.train_step, the asynchronous poll of the fp16-stream clamp counters (every 16 optimiser steps)
+    import time
+    batches = [batch(rng, 32, K, dev) for _ in range(8)]
+    for it in range(4):                                                         # new batch size: workspaces are allocated here
+        train_step(model2, criterion, optimizer2, *batches[it])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(96):
+        ld = train_step(model2, criterion, optimizer2, *batches[it % 8])
+        scheduler2.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 96
+    assert all(torch.isfinite(v) for v in ld.values()) and model2.stream16_saturation() == (0, 0)
+    print(f"96 steps at B = 32, K = {K}: {dt * 1e3:.2f} ms/step, clamp counters {model2.stream16_saturation()}")
     print("train_synthetic OK")
 
 
