@@ -955,6 +955,9 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
     // that the dispatcher could not place (its CU held by another stream's kernel: an RCCL channel) then finds the
     // list empty when it finally starts, instead of holding the launch up for a whole static list.
     const bool dyn = p.tile_queue != nullptr;
+    // end of this workgroup's list: a static list has walk.count tiles (the XCD-owned walk's lists end inside the tile range);
+    // a dynamic one runs until the counter passes the last tile
+    const int list_end = dyn ? total : walk.first + walk.count * walk.step;
     volatile int* tq = reinterpret_cast<volatile int*>(smem + 3 * N4_STAGE_BYTES);      // [2]: id of tile t in tq[t & 1] (behind the ring)
 
     if (wave >= 8) {
@@ -987,11 +990,11 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
         issue(rA, rB, 1, 1);
         int slot = 0;                                             // ring slot of the stage the compute waves multiply next
         int cur = walk.first;
-        for (int t = 0; cur < total; ++t) {
+        for (int t = 0; cur < list_end; ++t) {
             // the next tile: static list (first + (t + 1) step), or -- dynamic -- the id compute wave 0 fetched during this tile's
             // first K iteration and parked in tq[(t + 1) & 1] (published by the barrier of iteration 1; nk >= 3)
             int nxt = dyn ? total : cur + walk.step;
-            bool has_next = !dyn && nxt < total;
+            bool has_next = !dyn && nxt < list_end;
             if (has_next) desc_tile(nxt, rA2, rB2);
             for (int kt = 0; kt < nk; ++kt) {
                 // this wave's part of stage (t, kt) has landed; the following stage (issued already) may be in flight
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
     const int e_r = lane >> 3, e_c = (lane & 7) * 8;
     int slot = 0;
     int cur = walk.first;
-    for (int t = 0; cur < total; ++t) {
+    for (int t = 0; cur < list_end; ++t) {
         int tm, tn;
         persist_coords(p, cur, tm, tn);
         const int m0 = tm * BM, n0 = tn * N4_BN;
