@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .functional import attach_lengths, fused_contrastive_losses, fused_head_ok, logits_from_features, tokens_to_device
+from .functional import (attach_lengths, fused_contrastive_losses, fused_head_ok, logits_from_features, small_contrastive_losses,
+                         small_head_ok, tokens_to_device)
 from .losses import CriterionAlignment, CriterionContrastive
 
 
@@ -37,6 +38,11 @@ def _contrastive_from_features(model, criterion, fi, ft, labels_per_image, label
     logits = int(fi.shape[0]) * int(ft.shape[0]) * (D.world_size() if dist_global else 1)
     fused = (force != "0" and (force == "1" or logits >= (1 << 17)) and getattr(criterion, "kind", None) == "ce"
              and model.constrastive_overbatch and fused_head_ok(model.embed_dim))
+    # below that size, in one process: the three-launch head (CE_SMALL_HEAD=0 or CE_FUSED_HEAD=0: the general logits + criterion path)
+    if (not dist_global and not fused and force == "" and os.environ.get("CE_SMALL_HEAD", "1") != "0"
+            and getattr(criterion, "kind", None) == "ce" and model.constrastive_overbatch and index_pos is not None
+            and small_head_ok(fi, ft, index_pos)):
+        return small_contrastive_losses(fi, ft, model.logit_scale, labels_per_image, labels_per_text, index_pos)
     fi_all, ft_all = D.gather_feature_pair(fi, ft) if dist_global else (fi, ft)
     if fused:
         return fused_contrastive_losses(fi, ft, fi_all, ft_all, model.logit_scale, labels_per_image, labels_per_text, index_pos)

@@ -662,6 +662,61 @@ class InfoNCEPairFn(torch.autograd.Function):
         return dfi, dft, dls[0].reshape(()), None, None, None
 
 
+def small_head_ok(fi, ft, index_pos) -> bool:
+    """Shapes the three-launch head (csrc/head_small.hip) takes."""
+    nI, E = fi.shape
+    nT = ft.shape[0]
+    nsel = nT if index_pos is None else int(index_pos.shape[0])
+    return (fi.dim() == 2 and ft.dim() == 2 and ft.shape[1] == E and 1 <= nI <= 1024 and 1 <= nT <= 1024 and 1 <= nsel <= nT
+            and E % 4 == 0 and E <= 1024)
+
+
+class SmallHeadFn(torch.autograd.Function):
+    """Normalisation + logits over the batch + CriterionContrastive('ce') (model_clip.py:496-521, :633-662) as ONE node of three
+    launches -- two in the forward, one in the backward -- for batches whose logits matrix is small (config 2: 256 x 256):
+    between the towers' forward and backward nothing else runs, and the general head is 21 launches / 200 us there."""
+
+    @staticmethod
+    def forward(ctx, fi, ft, logit_scale, labels_i, labels_t, sel):
+        cl, s = lib(), stream()
+        dev = fi.device
+        fi, ft = _f32(fi), _f32(ft)
+        nI, E = fi.shape
+        nT = ft.shape[0]
+        labels_i = labels_i.to(device=dev, dtype=torch.int64).contiguous()
+        labels_t = labels_t.to(device=dev, dtype=torch.int64).contiguous()
+        sel = sel.to(device=dev, dtype=torch.int64).contiguous() if sel is not None else None
+        nsel = nT if sel is None else int(sel.shape[0])
+        cl.ce_head_small_workspace_floats.restype = ctypes.c_size_t
+        cl.ce_head_small_scalars_offset.restype = ctypes.c_size_t
+        dims = (c_int(nI), c_int(nT), c_int(nsel), c_int(E))
+        ws = _empty((int(cl.ce_head_small_workspace_floats(*dims)),), torch.float32, dev)
+        off = int(cl.ce_head_small_scalars_offset(*dims))
+        ls = logit_scale.detach().reshape(1)
+        check(cl.ce_head_small_fwd(ptr(fi), ptr(ft), c_int(nI), c_int(nT), c_int(E), ptr(ls), ptr(labels_i), ptr(labels_t), ptr(sel),
+                                   c_int(nsel), ptr(ws), s), "ce_head_small_fwd")
+        ctx.saved = (ws, ls, sel, (nI, nT, nsel, E))
+        return ws[off], ws[off + 1]
+
+    @staticmethod
+    def backward(ctx, g_i, g_t):
+        cl, s = lib(), stream()
+        ws, ls, sel, (nI, nT, nsel, E) = ctx.saved
+        dev = ws.device
+        g_i = None if g_i is None else g_i.float()
+        g_t = None if g_t is None else g_t.float()
+        dfi, dft = _empty((nI, E), torch.float32, dev), _empty((nT, E), torch.float32, dev)
+        dls = _empty((1,), torch.float32, dev)
+        check(cl.ce_head_small_bwd(c_int(nI), c_int(nT), c_int(nsel), c_int(E), ptr(ls), ptr(g_i), ptr(g_t), ptr(sel), ptr(ws),
+                                   ptr(dfi), ptr(dft), ptr(dls), s), "ce_head_small_bwd")
+        return dfi, dft, dls.reshape(()), None, None, None
+
+
+def small_contrastive_losses(fi, ft, logit_scale, labels_per_image, labels_per_text, index_pos):
+    loss_i, loss_t = SmallHeadFn.apply(fi, ft, logit_scale, labels_per_image, labels_per_text, index_pos)
+    return {"loss_i": loss_i, "loss_t": loss_t}
+
+
 def fused_contrastive_losses(fi, ft, fi_all, ft_all, logit_scale, labels_per_image, labels_per_text, index_pos):
     """``CriterionContrastive('ce')`` over the batch on raw features: loss_i = CE(s I^ T_all^T, labels_per_image),
     loss_t = CE over the ``index_pos`` rows of s T^ I_all^T (model_clip.py:633-662), the logits never materialised."""

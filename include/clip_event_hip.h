@@ -410,6 +410,23 @@ int ce_infonce_bwd(const float* q, long ldq, const int64_t* sel, int nq, const f
                    const float* logit_scale, const int64_t* labels, const float* lse, const float* grad, float* dq, float* dk,
                    float* dlogit_scale, void* stream);
 
+/* Small-batch contrastive head in three launches: feature normalisation, logits_per_image / logits_per_text over the batch
+ * (model_clip.py:496-521), CriterionContrastive 'ce' with index_pos (model_clip.py:633-662) and the whole backward down to the raw
+ * features, in fp32 -- for the sizes where the head between the towers' forward and backward is pure launch latency (config 2:
+ * 256 x 256 logits, 21 launches / 200 us in head.hip's form).  1 <= nI, nT <= 1024, nsel <= nT, E <= 1024 and a multiple of 4.
+ *   fi [nI,E], ft [nT,E] raw features; labels_i [nI] target column of image row i; sel [nsel] (nullable: rows 0..nsel-1) the text rows
+ *   that carry a loss, labels_t [nT] the target column of every text row (row sel[r] uses labels_t[sel[r]], as ce_xent_fwd does).
+ * ce_head_small_fwd fills `workspace` (ce_head_small_workspace_floats floats): normalised features, P = (softmax - onehot) / rows
+ * of both directions and, at ce_head_small_scalars_offset, four floats {loss_i, loss_t, sum P_i * lpi, sum P_t * lpt}.
+ * ce_head_small_bwd takes the upstream gradients of the two losses as DEVICE scalars (nullable = 0) and writes dfi, dft and
+ * *dlogit_scale (nullable). */
+size_t ce_head_small_workspace_floats(int nI, int nT, int nsel, int E);
+size_t ce_head_small_scalars_offset(int nI, int nT, int nsel, int E);
+int ce_head_small_fwd(const float* fi, const float* ft, int nI, int nT, int E, const float* logit_scale, const int64_t* labels_i,
+                      const int64_t* labels_t, const int64_t* sel, int nsel, float* workspace, void* stream);
+int ce_head_small_bwd(int nI, int nT, int nsel, int E, const float* logit_scale, const float* g_i, const float* g_t,
+                      const int64_t* sel, const float* workspace, float* dfi, float* dft, float* dlogit_scale, void* stream);
+
 /* Region / argument InfoNCE of the train_arg branch (model_clip.py:456-488) for every image of the batch in one
  * launch.  region / desc / label: f32 [R,E] rows grouped per image, image g owning rows offsets[g] .. offsets[g+1]-1 (at
  * most 16; max_rows = the largest group, checked on the host); label may be NULL when use_label = 0.  Adds

@@ -185,6 +185,40 @@ def test_fused_head_equals_logits_plus_criterion_path():
     assert rel < 5e-3
 
 
+def test_small_head_equals_logits_plus_criterion_path():
+    """ViT-B/32, B = 16, K = 1 and K = 3: the three-launch head engine.train_step takes below 2^17 logits (csrc/head_small.hip)
+    and the reference-shaped path (logits + CriterionContrastive; CE_SMALL_HEAD=0) give the same losses (1e-5) and the same
+    parameter gradients to bf16 rounding (relative 5e-3: the two fp32 heads agree to 1e-6, the towers' backward rounds the
+    feature gradient to bf16 first)."""
+    import os
+    from clip_event_amd import synthetic as S, distributed as D
+    from clip_event_amd.engine import contrastive_step_losses
+    from clip_event_amd.losses import CriterionContrastive
+    m = S.synthetic_model("vit_b32", seed=3).to(DEV)
+    crit = CriterionContrastive("ce")
+    for B, K in ((16, 1), (8, 3)):
+        img = S.synthetic_images(B, 224, seed=5).to(DEV)
+        txt = S.synthetic_tokens(B * K, 77, 49408, seed=6).to(DEV)
+        yi, yt, ip = D.global_labels(B, 1, K - 1, True, device=DEV, rank_=0)
+        out = {}
+        for small in ("1", "0"):
+            os.environ["CE_SMALL_HEAD"] = small
+            try:
+                m.zero_grad()
+                ld = contrastive_step_losses(m, crit, img, txt, yi, yt, ip)
+                sum(ld.values()).backward()
+                torch.cuda.synchronize()
+                out[small] = ({k: float(v) for k, v in ld.items()}, m._flat_grad.clone())
+            finally:
+                os.environ.pop("CE_SMALL_HEAD", None)
+        print("small head", out["1"][0], "general head", out["0"][0])
+        for k in ("loss_i", "loss_t"):
+            assert abs(out["1"][0][k] - out["0"][0][k]) < 1e-5 * max(1.0, abs(out["0"][0][k]))
+        rel = float((out["1"][1] - out["0"][1]).norm() / out["0"][1].norm())
+        print("flat gradient rel-l2 small vs general head:", rel)
+        assert rel < 5e-3
+
+
 def test_full_size_fp16_stream_step(vitb32):
     """The benchmarked shape (B = 256) with the residual / gradient stream in IEEE fp16 (model.stream16) against the fp32
     stream on the SAME weights and batch: same loss (1e-3), every tower's gradient within the bf16-operand noise floor of

@@ -896,3 +896,45 @@ def test_layernorm_emits_the_fp8_operand_copy(M, D):
                                     ptr(gs), c_int(M), c_int(D), ptr(q8), c_long(D), ptr(qs), stream()), "ln_bwd_q8")
     q_ref, s_ref = ops.quant_rows_fp8(dxb)
     assert torch.equal(q8, q_ref) and torch.equal(qs, s_ref)
+
+
+@pytest.mark.parametrize("nI,K,E,partial_sel", [(256, 1, 512, False), (8, 3, 512, False), (37, 3, 64, True), (200, 5, 768, True), (1, 1, 128, False)])
+def test_small_head_against_pytorch(nI, K, E, partial_sel):
+    """The three-launch head (csrc/head_small.hip: normalise, logits over the batch, 'ce' criterion with index_pos, and the whole
+    backward down to the raw features) against fp32 PyTorch autograd of model_clip.py:496-521 + :633-662: both losses, both
+    feature gradients and the logit_scale gradient, for config 2's shape, hard negatives (index_pos selects every K-th text
+    row), ragged sizes, a selection that skips rows, a single image, and unequal upstream weights of the two losses."""
+    from clip_event_amd.functional import SmallHeadFn, small_head_ok
+    rng = np.random.default_rng(nI * 7 + K + E)
+    nT = nI * K
+    fi0 = _randn(rng, nI, E)
+    ft0 = _randn(rng, nT, E)
+    ls0 = torch.tensor(float(np.log(1 / 0.07)))
+    sel = torch.arange(0, nT, K)
+    if partial_sel:
+        sel = sel[torch.from_numpy(rng.permutation(nI)[: max(1, nI // 2)].copy()).sort().values]
+    yi = torch.from_numpy(rng.integers(0, nT, size=nI))
+    yt = torch.from_numpy(rng.integers(0, nI, size=nT))              # one label per text row; the selected rows' are used
+    w_i, w_t = 1.0, 0.37
+
+    def ref():
+        fi, ft, ls = fi0.clone().requires_grad_(True), ft0.clone().requires_grad_(True), ls0.clone().requires_grad_(True)
+        In, Tn = fi / fi.norm(dim=-1, keepdim=True), ft / ft.norm(dim=-1, keepdim=True)
+        lpi = ls.exp() * In @ Tn.t()
+        lpt = ls.exp() * Tn @ In.t()
+        li = torch.nn.functional.cross_entropy(lpi, yi)
+        lt = torch.nn.functional.cross_entropy(lpt.index_select(0, sel), yt.index_select(0, sel))
+        (w_i * li + w_t * lt).backward()
+        return li.item(), lt.item(), fi.grad, ft.grad, ls.grad
+
+    fi, ft, ls = fi0.to(DEV).requires_grad_(True), ft0.to(DEV).requires_grad_(True), ls0.to(DEV).requires_grad_(True)
+    assert small_head_ok(fi, ft, sel)
+    li, lt = SmallHeadFn.apply(fi, ft, ls, yi.to(DEV), yt.to(DEV), sel.to(DEV))
+    (w_i * li + w_t * lt).backward()
+    torch.cuda.synchronize()
+    rli, rlt, rfi, rft, rls = ref()
+    print(f"loss_i {float(li):.6f} / {rli:.6f}  loss_t {float(lt):.6f} / {rlt:.6f}")
+    assert abs(float(li) - rli) < 2e-5 * max(1.0, abs(rli)) and abs(float(lt) - rlt) < 2e-5 * max(1.0, abs(rlt))
+    assert _report("small head dfi", fi.grad.cpu(), rfi)[1] < 2e-5
+    assert _report("small head dft", ft.grad.cpu(), rft)[1] < 2e-5
+    assert abs(float(ls.grad) - float(rls)) < 2e-5 * max(1.0, abs(float(rls)))
