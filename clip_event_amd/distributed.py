@@ -145,6 +145,99 @@ def reduce_dict(input_dict: Dict[str, torch.Tensor], average: bool = True) -> Di
         return {k: v for k, v in zip(names, values)}
 
 
+def piece_cuts(layers: int, pieces: int):
+    """Blocks at which a tower's gradient range is cut into ``pieces`` roughly equal groups of residual blocks (descending)."""
+    cuts = sorted({(layers * k) // pieces for k in range(1, pieces)}, reverse=True)
+    return [c for c in cuts if 0 < c < layers]
+
+
+class ShardPlan:
+    """Static partition of the flat parameter / gradient / moment buffers for the sharded optimiser step (lever 2):
+    every tower's range is cut into the SAME pieces the gradient exchange uses (``piece_cuts``), every piece into ``W`` equal
+    shards, and rank r owns shard r of every piece -- for good: its Adam moments never move.  A piece is the unit of the
+    reduce-scatter (gradients, in place: the reduced shard lands where the rank's own part of the piece lies) and of the
+    all-gather (updated fp32 masters, in place).  The layout puts every possible piece boundary on a multiple of 512
+    elements (model._prepare), so W = 2, 4, 8 split a piece into whole 64-element groups."""
+
+    def __init__(self, model, pieces: int, W: int):
+        self.W = W
+        self.pieces = []
+        for tower in GradSync.TOWERS:
+            a, b = model._ranges[tower]
+            ends = model._layer_end[tower]
+            bounds = [a] + [ends[c] for c in piece_cuts(len(ends), pieces)] + [b]
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                if hi > lo:
+                    if (hi - lo) % W:
+                        raise RuntimeError(f"a gradient piece of {hi - lo} elements does not split into {W} equal shards "
+                                           "(the flat layout supports world sizes 2, 4 and 8 for the sharded optimiser)")
+                    self.pieces.append((lo, hi))
+        self.head = model._ranges["head"]
+
+    def shard(self, piece, r: int):
+        lo, hi = piece
+        s = (hi - lo) // self.W
+        return lo + r * s, lo + (r + 1) * s
+
+    def owned(self, r: int):
+        return [self.shard(p, r) for p in self.pieces]
+
+    def split(self, a: int, b: int):
+        """The pieces that make up [a, b) (whose ends are piece boundaries)."""
+        out = [p for p in self.pieces if a <= p[0] and p[1] <= b]
+        if sum(hi - lo for lo, hi in out) != b - a:
+            raise RuntimeError(f"range [{a}, {b}) is not a union of gradient pieces")
+        return out
+
+
+def _reduce_scatter_mean(buf: torch.Tensor, W: int, r: int, async_op: bool):
+    """Mean reduce-scatter of ``buf`` in place: rank r's shard of the result lands in ``buf[r s : (r + 1) s]``."""
+    s = buf.numel() // W
+    if dist.get_backend() == "gloo":              # rehearsal backend: no reduce-scatter -- all-reduce (a superset of the result)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.div_(W)
+        return None
+    return dist.reduce_scatter_tensor(buf[r * s:(r + 1) * s], buf, op=dist.ReduceOp.AVG, async_op=async_op)
+
+
+def _all_gather_in_place(buf: torch.Tensor, W: int, r: int, async_op: bool = False):
+    """``buf`` = W equal shards; every rank contributes its own (shard r) and receives the others in place."""
+    s = buf.numel() // W
+    if dist.get_backend() == "gloo":
+        view = buf.view(torch.int16) if buf.dtype in (torch.bfloat16, torch.uint16) else buf      # (gloo moves bytes; it has no bf16 / u16)
+        dist.all_gather(list(view.chunk(W)), view[r * s:(r + 1) * s].clone())
+        return None
+    return dist.all_gather_into_tensor(buf, buf[r * s:(r + 1) * s], async_op=async_op)
+
+
+def sharded_update(plan: ShardPlan, params: torch.Tensor, sumsq: Optional[torch.Tensor], sumsq_fn, adam_fn):
+    """The optimiser step over a reduce-scattered gradient buffer.  ``sumsq_fn(lo, hi)`` adds the sum of squares of the
+    gradients ``[lo, hi)`` to ``sumsq`` (a device scalar, zeroed here; None: no clipping), ``adam_fn(lo, hi)`` applies
+    clip + Adam to that range reading ``sumsq`` -- the caller's kernels (optim.FusedAdam: ce_sumsq / ce_adam_step).  Every
+    rank updates its own shard of every piece (and the replicated head range, whose gradient was all-reduced), the global
+    gradient norm costs one scalar all-reduce, and the flat fp32 parameter buffer ``params`` is completed by an all-gather
+    in place, piece by piece.  (The masters, not the bf16 operand mirror, travel: the forward reads embeddings, LayerNorm
+    parameters and biases in fp32, and a checkpoint can then be written from any rank; the wire carries what the all-reduce
+    carried, each rank's Adam pass shrinks to 1 / W.  Only the Adam moments stay sharded: ``consolidate``.)"""
+    W, r = world_size(), rank()
+    owned = plan.owned(r)
+    if sumsq is not None:
+        sumsq.zero_()
+        for lo, hi in owned:
+            sumsq_fn(lo, hi)
+        dist.all_reduce(sumsq, op=dist.ReduceOp.SUM)
+        if plan.head[1] > plan.head[0]:
+            sumsq_fn(*plan.head)
+    for lo, hi in owned:
+        adam_fn(lo, hi)
+    if plan.head[1] > plan.head[0]:
+        adam_fn(*plan.head)
+    handles = [_all_gather_in_place(params[lo:hi], W, r, async_op=True) for lo, hi in plan.pieces]
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
 class GradSync:
     """Mean all-reduce of the flat gradient buffer, bucketed per tower and, inside a tower, per group of
     residual blocks -- the drop-in's counterpart of ``DistributedDataParallel``'s reducer (train.py:222-225).
@@ -168,8 +261,9 @@ class GradSync:
     no-op)."""
 
     TOWERS = ("visual", "text")
+    plan = None          # ShardPlan of the sharded optimiser step, when switched on
 
-    def __init__(self, model, pieces_per_tower: Optional[int] = None, auto_finish: bool = True):
+    def __init__(self, model, pieces_per_tower: Optional[int] = None, auto_finish: bool = True, sharded: Optional[bool] = None):
         self.model = model
         if pieces_per_tower is None:
             pieces_per_tower = int(os.environ.get("CE_GRAD_PIECES", "3"))
@@ -177,6 +271,17 @@ class GradSync:
         self.auto_finish = auto_finish
         self.pending = []
         self._reset()
+        # Sharded optimiser step (lever 2; CE_SHARDED_ADAM=1 or sharded=True): the pieces are reduce-SCATTERED, every
+        # rank runs clip + Adam on its own shard of every piece (optim.FusedAdam.step sees ``self.plan``) and the fp32 masters
+        # are all-gathered -- the all-reduce's bytes on the wire, 1 / W of the Adam pass per rank.  Only the Adam moments are
+        # then current on their owner alone, until ``consolidate()`` gathers them (checkpoints).
+        if sharded is None:
+            sharded = os.environ.get("CE_SHARDED_ADAM", "0") == "1"
+        self.plan = None
+        if sharded and is_dist() and world_size() > 1:
+            if getattr(model, "_ranges", None) is None and hasattr(model, "_ready"):
+                model._ready()                   # the plan is cut from the flat layout
+            self.plan = ShardPlan(model, self.pieces, world_size())
         model.grad_sync = self            # callable: (model, tower, upto_layer=None); also queried for layer_cuts
         # With a process group live, RCCL's channel kernels will sit on some CUs while the backward runs: hand the persistent
         # GEMMs' tiles out dynamically, so that a workgroup the dispatcher could not place does not hold a launch up for a whole
@@ -210,14 +315,19 @@ class GradSync:
         None for any pass but the last one through the tower (its range will be written again)."""
         if not active() or self.pieces < 2 or tower in self.done or not self._is_last_pass(tower):
             return []
-        cuts = sorted({(layers * k) // self.pieces for k in range(1, self.pieces)}, reverse=True)
-        return [c for c in cuts if 0 < c < layers]
+        return piece_cuts(layers, self.pieces)
 
     def _reduce_range(self, a: int, b: int, async_op: bool):
         if b <= a:
             return
-        buf = self.model._flat_grad[a:b]
         W = world_size()
+        if self.plan is not None and (a, b) != tuple(self.plan.head):
+            for lo, hi in self.plan.split(a, b):
+                h = _reduce_scatter_mean(self.model._flat_grad[lo:hi], W, rank(), async_op)
+                if async_op and h is not None:
+                    self.pending.append(h)
+            return
+        buf = self.model._flat_grad[a:b]
         if dist.get_backend() == "gloo":
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
             buf.div_(W)
@@ -298,6 +408,20 @@ class GradSync:
         self._reset()
 
 
+def consolidate(model, optimizer):
+    """COLLECTIVE (every rank calls it): after sharded optimiser steps, gather both Adam moments from their owners so that
+    ``optimizer.state_dict()`` -- the 'optimizer' entry of a checkpoint -- can be taken on any rank.  (The parameters
+    themselves are whole on every rank after every step.)  No-op when nothing is stale."""
+    plan = getattr(getattr(model, "grad_sync", None), "plan", None)
+    if plan is None or not getattr(optimizer, "_moments_stale", False):
+        return
+    W, r = world_size(), rank()
+    for buf in (optimizer.m, optimizer.v):
+        for lo, hi in plan.pieces:
+            _all_gather_in_place(buf[lo:hi], W, r)
+    optimizer._moments_stale = False
+
+
 class DistributedDataParallel(torch.nn.Module):
     """Call-site replacement for ``torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu],
     find_unused_parameters=True)`` (train.py:222-225).  torch's own wrapper cannot drive this model: its reducer
@@ -308,13 +432,13 @@ class DistributedDataParallel(torch.nn.Module):
     ``backward()`` returns -- by installing ``GradSync``.  Extra torch keyword arguments are accepted and ignored."""
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True, process_group=None,
-                 bucket_cap_mb=None, find_unused_parameters=False, **ignored):
+                 bucket_cap_mb=None, find_unused_parameters=False, sharded_optimizer: Optional[bool] = None, **ignored):
         super().__init__()
         if process_group is not None:
             raise NotImplementedError("only the default process group is supported")
         self.module = module
         self.device_ids = device_ids
-        self.grad_sync = GradSync(module)
+        self.grad_sync = GradSync(module, sharded=sharded_optimizer)
         if is_dist() and world_size() > 1:      # DDP broadcasts rank 0's parameters at construction
             with torch.no_grad():
                 for p in module.parameters():
@@ -324,3 +448,7 @@ class DistributedDataParallel(torch.nn.Module):
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def consolidate(self, optimizer):
+        """Collective: see ``distributed.consolidate``."""
+        consolidate(self.module, optimizer)

@@ -327,8 +327,13 @@ class CLIP(nn.Module):
                                 ("ln_final.", "text_projection"), ("positional_embedding", "token_embedding.")),
         }
         ranges, layer_end = {}, {}
+        # every boundary a gradient piece can end on (tower start / end, the end of every block) is a multiple of 8 x 64 elements:
+        # a piece then splits into 2, 4 or 8 equal shards of whole 64-element groups (distributed.ShardPlan: reduce-scatter +
+        # sharded Adam + all-gather of the bf16 mirror)
+        PIECE = 512
         for group in ("head", "visual", "text"):
             head, per_block, blocks, tail = groups[group]
+            off = (off + PIECE - 1) // PIECE * PIECE
             start = off
             layer_end[group] = {}
             for n in head:
@@ -338,10 +343,12 @@ class CLIP(nn.Module):
                 for n in names_b:
                     offsets[n] = off
                     off += (pmap[n].numel() + 63) // 64 * 64
+                off = (off + PIECE - 1) // PIECE * PIECE
                 layer_end[group][b] = off          # gradients of blocks >= b (and the output side) end here
             for n in tail:
                 offsets[n] = off
                 off += (pmap[n].numel() + 63) // 64 * 64
+            off = (off + PIECE - 1) // PIECE * PIECE
             ranges[group] = (start, off)
         if len(offsets) != len(named):
             raise RuntimeError("flat layout lost a parameter")

@@ -73,6 +73,60 @@ def wrapper_case(rank, W, dev, sd, cfg, B, img_all, txt_all, crit):
     sys.exit(0 if int(flag) == 1 else 1)
 
 
+def sharded_case(rank, W, dev, sd, B, shard, crit):
+    """DESIGN 5 lever 2 on the HIP path: three `train_step`s with `GradSync(sharded=True)` (reduce-scattered pieces, clip + Adam on
+    the own shards, all-gather of the masters) against the same steps with the all-reduce + replicated update.  Adam with
+    eps = 1 so that the update is smooth in the gradient (the atomics' last-bit noise is otherwise amplified to 2 lr per
+    element, tests/test_model_gpu.py::test_deferred_text_update_equals_the_one_launch_update)."""
+    from clip_event_amd import distributed as D
+    from clip_event_amd.engine import train_step
+    from clip_event_amd.model import build_model
+    from clip_event_amd.optim import FusedAdam
+    args, kw = shard(rank * B, (rank + 1) * B, rank, W)
+    out = {}
+    for mode in (False, True):
+        m = build_model({k: v.clone() for k, v in sd.items()}).to(dev)
+        m.set_hyps(True, False, False)
+        sync = D.GradSync(m, sharded=mode)
+        assert (sync.plan is not None) == mode
+        opt = FusedAdam(m, lr=0.1, eps=1.0, max_norm=1.0)
+        for it in range(3):
+            train_step(m, crit, opt, *args, grad_sync=sync, **kw)
+        torch.cuda.synchronize()
+        if mode:
+            try:
+                opt.state_dict()
+                raise AssertionError("state_dict() of sharded moments did not refuse")
+            except RuntimeError as e:
+                assert "consolidate" in str(e)
+            D.consolidate(m, opt)
+            opt.state_dict()
+        with torch.no_grad():
+            li, lt = m(args[0], args[1])
+        out[mode] = (m._flat.detach().clone(), opt.m.clone(), opt.v.clone(), float(opt.grad_norm()), li.float().clone())
+    ok = True
+    for i, what in enumerate(("masters", "exp_avg", "exp_avg_sq")):
+        a, b = out[True][i], out[False][i]
+        rel = float((a - b).norm() / b.norm())
+        print(f"[sharded] rank {rank} {what}: sharded vs replicated rel-l2 {rel:.3e}", flush=True)
+        ok &= rel < (1e-4 if i == 0 else 2e-2)
+    print(f"[sharded] rank {rank} grad norm {out[True][3]:.6f} vs {out[False][3]:.6f}", flush=True)
+    ok &= abs(out[True][3] - out[False][3]) <= 1e-2 * abs(out[False][3])      # (third step: bf16-level noise of two steps behind it)
+    rel = float((out[True][4] - out[False][4]).norm() / out[False][4].norm())
+    print(f"[sharded] rank {rank} logits after the steps: rel-l2 {rel:.3e}", flush=True)
+    ok &= rel < 2e-2
+    # every rank holds the same masters
+    mx = out[True][0].clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    ok &= bool(torch.equal(mx, out[True][0]))
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(f"[sharded] {'OK' if float(flag) == 1.0 else 'FAILED'}", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if float(flag) == 1.0 else 1)
+
+
 def main():
     rank, W = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     case = os.environ.get("CASE", "k1")
@@ -113,6 +167,8 @@ def main():
 
     if case == "wrapper":
         return wrapper_case(rank, W, dev, sd, cfg, B, img_all, txt_all, crit)
+    if case == "sharded":
+        return sharded_case(rank, W, dev, sd, B, shard, crit)
 
     # ---- the W-rank step: real GradSync, every collective of the path ----
     m = build_model({k: v.clone() for k, v in sd.items()}).to(dev)

@@ -45,7 +45,7 @@ def run_ranks(script, case, W=2, timeout=420, extra_env=None):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("case", ["k1", "k5", "align", "region", "all", "wrapper"])
+@pytest.mark.parametrize("case", ["k1", "k5", "align", "region", "all", "wrapper", "sharded"])
 def test_two_rank_step_equals_concatenated_batch(case):
     rcs, outs = run_ranks("ddp_child.py", case)
     print(outs[0][-3000:])

@@ -88,8 +88,8 @@ class _FlatStandIn:
     prefix ends (model.CLIP._prepare)."""
     LAYERS = 4
 
-    def __init__(self):
-        blk, headn, tail = 6, 2, 3
+    def __init__(self, tail=3):
+        blk, headn = 6, 2
         self._ranges, self._layer_end = {}, {}
         off = 0
         self._ranges["head"] = (off, off + 1)
@@ -214,3 +214,95 @@ def test_ddp_wrapper_surface_and_torch_ddp_is_refused():
             m._note_pass("visual")
     finally:
         P.DistributedDataParallel._active_ddp_module = None
+
+
+# ---- sharded optimiser step (DESIGN 5 lever 2): reduce-scatter + per-shard clip / Adam + all-gather of the masters ----------
+
+def _adam_reference(p, g, m, v, coef, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    g = g * coef
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_(lr / (1 - b1 ** step) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
+
+
+def _sharded_worker(rank, W, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from clip_event_amd import distributed as D
+    m = _FlatStandIn(tail=4)                                   # every piece splits into two equal shards
+    n = m._flat_grad.numel()
+    m._flat = torch.randn(n, generator=torch.Generator().manual_seed(5))
+    sync = D.GradSync(m, pieces_per_tower=3, sharded=True)
+    plan = sync.plan
+    assert plan is not None and len(plan.pieces) == 6 and plan.head == (0, 1)
+    owned = plan.owned(rank)
+    mine = torch.zeros(n, dtype=torch.bool)
+    for lo, hi in owned:
+        mine[lo:hi] = True
+    mine[0] = True
+    mom, var = torch.zeros(n), torch.zeros(n)
+    sumsq = torch.zeros(1)
+    lr, max_norm = 0.05, 1.0
+    grads = []
+    for step in range(1, 4):
+        m._flat_grad.zero_()
+        g = torch.Generator().manual_seed(100 * step + rank)
+        contrib = {t: torch.randn(m._ranges[t][1] - m._ranges[t][0], generator=g) for t in ("visual", "text")}
+        for t in ("visual", "text"):
+            sync.note_forward(t)
+        for t in ("text", "visual"):
+            m.backward_pass(t, contrib[t])
+        m._flat_grad[0] += float(rank + 1)
+        sync.finish()
+        grads.append(m._flat_grad.clone())
+        m._flat_grad[~mine] = float("nan")                     # what a real reduce-scatter leaves outside the own shards: nothing usable
+        touched = []
+
+        def sumsq_fn(lo, hi):
+            sumsq.add_(m._flat_grad[lo:hi].square().sum())
+
+        def adam_fn(lo, hi):
+            coef = min(1.0, max_norm / (float(sumsq.sqrt()) + 1e-6))
+            _adam_reference(m._flat[lo:hi], m._flat_grad[lo:hi], mom[lo:hi], var[lo:hi], coef, lr, step)
+            touched.append((lo, hi))
+
+        D.sharded_update(plan, m._flat, sumsq, sumsq_fn, adam_fn)
+        assert sorted(touched) == sorted(owned + [plan.head])
+        assert bool(torch.isfinite(m._flat).all())
+
+    class _Opt:
+        pass
+    opt = _Opt()
+    opt.m, opt.v, opt._moments_stale = mom, var, True
+    before = mom.clone()
+    D.consolidate(m, opt)
+    assert not opt._moments_stale and torch.equal(mom[mine], before[mine])
+    gathered = [None] * W
+    dist.all_gather_object(gathered, (m._flat, mom, var, grads))
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sharded_optimizer_step_equals_replicated_step(tmp_path):
+    """Reduce-scattered gradient pieces + clip / Adam on the own shard of every piece + all-gather of the masters leave every rank
+    with the parameters a replicated step (mean gradients, one clip + Adam over everything) produces, and `consolidate` the
+    moments.  Non-owned gradient shards are poisoned before the update: nothing may read them."""
+    W = 2
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_sharded_worker, args=(W, _free_port(), out), nprocs=W, join=True)
+    gathered = torch.load(out, weights_only=False)          # written by this test
+    m = _FlatStandIn(tail=4)
+    n = m._flat_grad.numel()
+    p = torch.randn(n, generator=torch.Generator().manual_seed(5))
+    mom, var = torch.zeros(n), torch.zeros(n)
+    for step in range(1, 4):
+        g = gathered[0][3][step - 1]                           # rank means, identical on both ranks (gloo all-reduces whole pieces)
+        assert torch.allclose(g, gathered[1][3][step - 1], atol=1e-7)
+        coef = min(1.0, 1.0 / (float(g.square().sum().sqrt()) + 1e-6))
+        _adam_reference(p, g, mom, var, coef, 0.05, step)
+    for r in range(W):
+        assert torch.allclose(gathered[r][0], p, atol=1e-6), r
+        assert torch.allclose(gathered[r][1], mom, atol=1e-6) and torch.allclose(gathered[r][2], var, atol=1e-6), r

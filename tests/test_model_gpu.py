@@ -1101,7 +1101,8 @@ def test_deferred_text_update_equals_the_one_launch_update(monkeypatch):
             rel, noise = float((a - b).norm() / b.norm()), float((c - b).norm() / b.norm())
             print(f"deferred vs one-launch update, {where}, {what}: rel-l2 {rel:.3e} (two one-launch runs: {noise:.3e})")
             # (moments: once two runs differ in a last bit, bf16 roundings downstream flip and the next gradients differ at the bf16 level)
-            assert rel < (1e-4 if what in ("masters", "bf16 mirror") else 3.0 * noise + 2e-3), (where, what)
+            # (bf16 mirror: one flipped rounding of a master is a bf16 ulp, 4e-3 of that element)
+            assert rel < (1e-4 if what == "masters" else 3.0 * noise + (1e-4 if what == "bf16 mirror" else 2e-3)), (where, what)
     # a step driven by hand after train_step (plain zero_grad / backward / step) still sees complete text gradients
     crit = CriterionContrastive("ce")
     for m, o in ((m1, o1), (m0, o0)):
