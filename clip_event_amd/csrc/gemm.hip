@@ -923,7 +923,11 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160lw_kernel(
 // of the tile's LAST stage (free until the barrier that opens the next tile's first iteration; one extra barrier per
 // tile makes sure every wave has finished reading it).  Needs K >= 128.
 // ------------------------------------------------------------------------------------------
-template <int EPI, int TM, int F8 = 0>
+// TS > 0: TWO TILE HEIGHTS in one launch -- row panels 0 .. p.tall_panels-1 are 32 TM rows tall, the others 32 TS (< TM); the ring
+// keeps the tall layout and the loaders their instruction count (a short tile's missing rows are out of its descriptor's range:
+// no memory traffic), the compute waves run a body specialised for the tile's height.  The launcher picks the split so that
+// every workgroup's list costs the same (launch_nt): 960 tiles of 160 rows = 3.75 rounds become 3 rounds of 160 + 1 of 128.
+template <int EPI, int TM, int F8 = 0, int TS = 0>
 __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(NTArgs p) {
     constexpr int BM = 32 * TM;
     constexpr int A_BYTES = BM * N4_BK * 2;
@@ -937,10 +941,17 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
     // the first 6 of a tile's 10 slots and loaded the rest on use: 7 VGPRs spilled at the 168-VGPR budget; 2 held slots
     // without the early requests cost the GELUGRAD class 6 %.)
     constexpr bool PF_AUX = EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_RESID_F16;
-    constexpr int NPQ = F8 ? 0 : ((EPI == CE_EPI_GELUGRAD_BF16 && TM >= 5) ? 1 : 2);   // slots requested under the last K iteration (GELUGRAD
-                                                     // also carries 8 column-sum registers: 2 spilled 3 VGPRs at TM = 5; the e4m3 form's
-                                                     // fragments are twice as wide: none)
-    constexpr int NSLOT = 2 * TM;
+    // NPQ (per tile height, below): slots requested under the last K iteration (GELUGRAD also carries 8 column-sum registers: 2
+    // spilled 3 VGPRs at TM = 5; the e4m3 form's fragments are twice as wide: none)
+    // first row and height of row panel tm
+    auto panel_m0 = [&](int tm) __attribute__((always_inline)) -> int {
+        if constexpr (TS > 0) return tm < p.tall_panels ? tm * BM : p.tall_panels * BM + (tm - p.tall_panels) * (32 * TS);
+        else return tm * BM;
+    };
+    auto panel_rows = [&](int tm) __attribute__((always_inline)) -> int {
+        if constexpr (TS > 0) return tm < p.tall_panels ? BM : 32 * TS;
+        else return BM;
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -971,8 +982,8 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
         auto desc_tile = [&](int tile, u32x4& rA, u32x4& rB) {
             int tm, tn;
             persist_coords(p, tile, tm, tn);
-            const int m0 = tm * BM, n0 = tn * N4_BN;
-            rA = make_rsrc_words(reinterpret_cast<const char*>(p.A) + (long)m0 * p.lda * ES, (uint32_t)((long)min(p.M - m0, BM) * p.lda * ES));
+            const int m0 = panel_m0(tm), n0 = tn * N4_BN;
+            rA = make_rsrc_words(reinterpret_cast<const char*>(p.A) + (long)m0 * p.lda * ES, (uint32_t)((long)min(p.M - m0, panel_rows(tm)) * p.lda * ES));
             rB = make_rsrc_words(reinterpret_cast<const char*>(p.B) + (long)n0 * p.ldb * ES, (uint32_t)((long)min(p.N - n0, N4_BN) * p.ldb * ES));
         };
         auto issue = [&](const u32x4& rA, const u32x4& rB, int slot, int kt) {
@@ -1020,19 +1031,22 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
 
     const int wm = wave >> 2, wn = wave & 3;
     const int f_row = lane & 15, f_kc = lane >> 4, f_sw = lane & 7;
-    const int fa_base = (wm * (TM * 16) + f_row) * 128;
     const int fb_base = A_BYTES + (wn * 64 + f_row) * 128;
     constexpr int EROW = 272;
     const int e_r = lane >> 3, e_c = (lane & 7) * 8;
     int slot = 0;
     int cur = walk.first;
-    for (int t = 0; cur < list_end; ++t) {
-        int tm, tn;
-        persist_coords(p, cur, tm, tn);
-        const int m0 = tm * BM, n0 = tn * N4_BN;
-        f32x4 acc[TM][4];
+    int t = 0;
+    // one tile of TMA x 32 rows (TMA = TM, or TS for a short tile): the body is specialised for the height
+    auto tile_body = [&](auto tma_c, int tm, int tn) __attribute__((always_inline)) {
+        constexpr int TMA = decltype(tma_c)::value;
+        constexpr int NPQ = F8 ? 0 : ((EPI == CE_EPI_GELUGRAD_BF16 && TMA >= 5) ? 1 : 2);
+        constexpr int NSLOT = 2 * TMA;
+        const int fa_base = (wm * (TMA * 16) + f_row) * 128;
+        const int m0 = panel_m0(tm), n0 = tn * N4_BN;
+        f32x4 acc[TMA][4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TMA; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int last = slot;
@@ -1041,7 +1055,7 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
             const char* st = smem + slot * STAGE_BYTES;
             last = slot;
             slot = slot == 2 ? 0 : slot + 1;
-            nt160_stage_mma<TM, F8>(st, fa_base, fb_base, f_kc, f_sw, acc);
+            nt160_stage_mma<TMA, F8>(st, fa_base, fb_base, f_kc, f_sw, acc);
         };
         // dynamic list: wave 0 requests the next tile id now (one returning atomic from lane 0; the other lanes' offsets are
         // out of the descriptor's range) and parks it in LDS after the first K iteration, where its latency has passed
@@ -1058,7 +1072,7 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
         const int gn = n0 + wn * 64 + e_c;
         const bool col_ok = gn < p.N;
         const int gnc = col_ok ? gn : 0;
-        const int e_row = wm * (TM * 16) + e_r, e_col = wn * 64 + e_c;
+        const int e_row = wm * (TMA * 16) + e_r, e_col = wn * 64 + e_c;
         constexpr int OB = epi_out_bytes(EPI);
         const EpiBuf eo = epi_buf(p.out, p.ldo, OB, p.M, p.N, m0, n0, e_row, e_col, col_ok);
         EpiBuf eo2 = eo, er = eo, ea = eo;
@@ -1100,7 +1114,7 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
         char* ebuf = smem + last * STAGE_BYTES + wave * (16 * EROW);
         f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TMA; ++i) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 *reinterpret_cast<f32x4*>(ebuf + (lane & 15) * EROW + (nt * 16 + 4 * (lane >> 4)) * 4) = acc[i][nt];
@@ -1163,6 +1177,16 @@ __global__ __launch_bounds__(64 * (8 + N4_LOADERS), 3) void gemm_nt160p_kernel(N
                               : e == 4 ? cs1[0] : e == 5 ? cs1[1] : e == 6 ? cs1[2] : cs1[3];
                 if (gn + e < p.N) atomicAdd(colsum + gn + e, v);
             }
+        }
+    };
+    for (; cur < list_end; ++t) {
+        int tm, tn;
+        persist_coords(p, cur, tm, tn);
+        if constexpr (TS > 0) {
+            if (tm < p.tall_panels) tile_body(std::integral_constant<int, TM>{}, tm, tn);
+            else tile_body(std::integral_constant<int, TS>{}, tm, tn);
+        } else {
+            tile_body(std::integral_constant<int, TM>{}, tm, tn);
         }
         // next tile: the static list, or the id wave 0 parked during this tile (every wave has passed a barrier since)
         cur = dyn ? __builtin_amdgcn_readfirstlane(tq[(t + 1) & 1]) : cur + walk.step;
@@ -1918,6 +1942,7 @@ int nt_variant() {   // CE_GEMM_NT=128|256 forces a tile; default: pick per shap
     return v;
 }
 
+int g_last_tall = 0, g_last_ts = 0;   // two-height plan of the latest persistent launch (ce_gemm_nt_last_plan)
 int g_force_chunk = -2;      // ce_gemm_nt_tune(1000 + ...): walk of the persistent kernel (-2: CE_NT_CHUNK / default)
 int g_force_tm = -1;
 int force_tm() {   // CE_GEMM_TM / ce_gemm_nt_tune(): 3..8 = tile height (x32 rows) of the 256-column kernel, 32 = the
@@ -2015,6 +2040,12 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+        if constexpr (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BF16) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+        }
     });
     const double out_b = (EPI == CE_EPI_F32 || EPI == CE_EPI_BIAS_F32) ? 4.0 : (EPI == CE_EPI_BIAS_RESID_F32 ? 8.0 : (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_RESID_F16 ? 4.0 : 2.0));
     CeProfScope prof(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI, 2.0 * a.M * a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + out_b * a.M * a.N, stream);
@@ -2100,6 +2131,58 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             // (the fetched id is published by the barrier of iteration 1 and needed from iteration nk - 2) on the launch-wide walk
             a.tile_queue = (g_dynamic && tiles > (long)grid.x && a.K >= 3 * N4_BK && a.tile_chunk == 0) ? next_tile_queue(stream) : nullptr;
             prof.retag(CE_PROF_GEMM_NT0 + CE_PROF_NT_FAMILIES * EPI + 6);
+            // TWO TILE HEIGHTS (gemm_nt160p_kernel<EPI, 5, 0, TS>): n_tall row panels of 160 rows, the rest in panels of 32 TS, chosen so
+            // that the longest per-workgroup list (tall tiles first, round-robin over the grid) is shortest under the same cost
+            // model; taken when it beats the best single height by >= 3 %.  12800 x 3072: 960 tiles of 160 rows = 3.75 rounds -> 3
+            // rounds of 160 + one of 128.  CE_NT_MIXED=0 switches it off.
+            g_last_tall = g_last_ts = 0;
+            constexpr bool mixed_epi = EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BF16;
+            if constexpr (mixed_epi) {
+                static const int mixed = getenv("CE_NT_MIXED") ? atoi(getenv("CE_NT_MIXED")) : 1;
+                if (mixed && f == 0 && strip == 0 && a.tile_chunk == 0 && a.M >= 320) {
+                    const long G = pgrid, tn = a.tiles_n;
+                    auto span = [&](long n_tall, int ts, long n_short) {      // cost of the longest list
+                        const long T = n_tall * tn, S = n_short * tn, q = T / G, r = T % G;
+                        auto shorts = [&](long d) { return d < S ? (S - 1 - d) / G + 1 : 0; };   // short tiles of the workgroup d places behind r
+                        const long c5 = 32 * 5 + 48, cs = 32 * ts + 48;
+                        long worst = q * c5 + shorts(0) * cs;                  // workgroup r: q tall tiles, the most short ones
+                        if (r > 0) worst = std::max(worst, (q + 1) * c5 + shorts(G - r) * cs);   // workgroup 0: q + 1 tall
+                        return worst;
+                    };
+                    long uniform = -1;
+                    for (int tm = 5; tm >= 3; --tm) {
+                        const long tiles_u = (long)ce_div_up(a.M, 32 * tm) * tn;
+                        const long c = ((tiles_u + G - 1) / G) * (32 * tm + 48);
+                        if (uniform < 0 || c < uniform) uniform = c;
+                    }
+                    long best = uniform, b_tall = -1, b_short = 0;
+                    int b_ts = 0;
+                    for (int ts = 4; ts >= 1; --ts)
+                        for (long n_tall = a.M / 160; n_tall >= 1; --n_tall) {
+                            const long rest = a.M - n_tall * 160;
+                            if (rest <= 0) continue;
+                            const long n_short = (rest + 32 * ts - 1) / (32 * ts);
+                            const long c = span(n_tall, ts, n_short);
+                            if (c < best) { best = c; b_tall = n_tall; b_short = n_short; b_ts = ts; }
+                        }
+                    if (b_tall > 0 && best * 100 <= uniform * 97) {
+                        a.tall_panels = (int)b_tall;
+                        g_last_tall = (int)b_tall; g_last_ts = b_ts;
+                        a.tiles_m = (int)(b_tall + b_short);
+                        const long tiles2 = (long)a.tiles_m * a.tiles_n;
+                        const dim3 grid2((unsigned)(tiles2 < pgrid ? tiles2 : pgrid));
+                        a.tile_queue = (g_dynamic && tiles2 > (long)grid2.x && a.K >= 3 * N4_BK) ? next_tile_queue(stream) : nullptr;
+                        switch (b_ts) {
+                            case 1: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5, 0, 1>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                            case 2: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5, 0, 2>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                            case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5, 0, 3>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                            default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 5, 0, 4>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                        }
+                        CE_LAUNCH_CHECK();
+                        return 0;
+                    }
+                }
+            }
             switch (ptm) {
                 case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3>), grid, block, N4P_LDS_BYTES, stream, a); break;
                 case 4: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4>), grid, block, N4P_LDS_BYTES, stream, a); break;
@@ -2272,6 +2355,13 @@ extern "C" int ce_gemm_set_dynamic_tiles(int on) {
 extern "C" int ce_gemm_set_cu_budget(int cus) {
     CE_CHECK_ARG(cus == 0 || (cus >= 32 && cus <= 256), "ce_gemm_set_cu_budget: 32..256 CUs, or 0 for the default (CE_GEMM_CUS / 256)");
     g_cus = cus ? cus : (getenv("CE_GEMM_CUS") ? atoi(getenv("CE_GEMM_CUS")) : 256);
+    return 0;
+}
+
+// two-height plan of the most recent persistent NT launch (tests): tall panels, short height in 32-row units (0, 0: one height)
+extern "C" int ce_gemm_nt_last_plan(int* tall_panels, int* short_tm) {
+    if (tall_panels) *tall_panels = g_last_tall;
+    if (short_tm) *short_tm = g_last_ts;
     return 0;
 }
 

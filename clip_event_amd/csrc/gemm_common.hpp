@@ -18,6 +18,8 @@ struct NTArgs {
     int tile_chunk = 0;          // persistent kernel: > 0 = XCD-owned walk in chunks of this many row panels (persist_walk)
     unsigned int* tile_queue = nullptr;   // persistent kernel: != null = DYNAMIC tile list -- a workgroup's first tile is its static one,
                                           // every further tile is grid + atomicAdd(*tile_queue, 1) (zeroed by the launcher)
+    int tall_panels = 0;         // persistent kernel, two tile heights (template TS > 0): row panels 0 .. tall_panels-1 are 32 TM rows
+                                 // tall, the rest 32 TS rows; tiles_m counts both kinds
     const float* sa = nullptr;   // fp8 path: per-row dequantisation scales of A (M) ...
     const float* sb = nullptr;   // ... and of B (N); the epilogue multiplies the accumulator by sa[m] * sb[n]
     const uint8_t* sa8 = nullptr;   // fp8 path, MX form: E8M0 block scales of A [M, K/32] ...

@@ -472,6 +472,9 @@ const char* ce_profile_class_name(int cls);
  * per workgroup), 162 = persistent loader waves (163..165: with 96/128/160-row tiles); 1000..1999 = tile walk of the
  * persistent kernel: 1000 XCD-owned chunks of tiles_m / 8 row panels, 1001 launch-wide (default), 1001 + n chunks of n */
 void ce_gemm_nt_tune(int variant);
+/* the two-height tile plan of the most recent persistent NT launch (tests): row panels of 160 rows, height of the others in
+ * 32-row units; 0, 0 when the launch used one height */
+int ce_gemm_nt_last_plan(int* tall_panels, int* short_tm);
 /* tuning hook (tools/ only): 0 auto, 4/5/6/8 = tile height (x32 rows) of the 256-column kernel, 105 = 160x128 tile */
 void ce_gemm_nt_fp8_tune(int variant);
 

@@ -938,3 +938,57 @@ def test_small_head_against_pytorch(nI, K, E, partial_sel):
     assert _report("small head dfi", fi.grad.cpu(), rfi)[1] < 2e-5
     assert _report("small head dft", ft.grad.cpu(), rft)[1] < 2e-5
     assert abs(float(ls.grad) - float(rls)) < 2e-5 * max(1.0, abs(float(rls)))
+
+
+@pytest.mark.parametrize("M,N,K,plan", [(12800, 3072, 768, (64, 4)), (11137, 2048, 512, None), (10807, 1536, 512, None),
+                                        (18200, 3072, 768, None), (12800, 2304, 768, (0, 0)), (7700, 2048, 256, None)])
+@pytest.mark.parametrize("dynamic", [0, 1])
+def test_gemm_nt_two_tile_heights(M, N, K, plan, dynamic):
+    """The persistent NT kernel with TWO tile heights in one launch (160-row panels first, the rest in panels of 32 TS rows,
+    split by `launch_nt` so that every workgroup's list costs the same): bit-identical to the one-height persistent kernel
+    (the same MFMA sequence per output element) for all four epilogues that have the form, guard rows untouched, with the
+    static and the dynamic tile list.  The plan the launcher took is read back (`ce_gemm_nt_last_plan`): 12800 x 3072 = 64
+    panels of 160 + 20 of 128 (3 rounds + 1 instead of 3.75 rounds of 160); 12800 x 2304 has no better split."""
+    from ctypes import byref, c_int
+    from clip_event_amd import ops, _lib as L
+    rng = np.random.default_rng(M + N + K)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    bias = _randn(rng, N)
+    aux = _randn(rng, M, N).to(torch.bfloat16)
+    A, B, AUX, BIAS = a.to(DEV), b.to(DEV), aux.to(DEV), bias.to(DEV)
+    lib = L.lib()
+    assert lib.ce_gemm_set_dynamic_tiles(dynamic) == 0
+
+    def run_all():
+        out = {}
+        guard = torch.full((M + 64, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(A, B, L.EPI_BF16, out=guard[:M])
+        out["bf16"] = guard[:M].clone()
+        tall, ts = c_int(-1), c_int(-1)
+        lib.ce_gemm_nt_last_plan(byref(tall), byref(ts))
+        out["bias_bf16"] = ops.gemm_nt(A, B, L.EPI_BIAS_BF16, bias=BIAS)
+        out["dact"], out["gelu"] = ops.gemm_nt(A, B, L.EPI_BIAS_GELU, bias=BIAS)
+        cs = torch.zeros(N, device=DEV)
+        out["gelugrad"] = ops.gemm_nt(A, B, L.EPI_GELUGRAD_BF16, aux=AUX, out2=cs)
+        out["colsum"] = cs
+        torch.cuda.synchronize()
+        assert bool((guard[M:] == 7.0).all()), "rows past M were written"
+        return out, (tall.value, ts.value)
+
+    try:
+        got, took = run_all()
+        print(f"two heights {M}x{N}x{K}: {took[0]} panels of 160 rows + panels of {32 * took[1]} rows")
+        if plan is not None:
+            assert took == plan, took
+        lib.ce_gemm_nt_tune(165)                  # one height: the persistent kernel with 160-row tiles
+        want, took1 = run_all()
+        assert took1 == (0, 0)
+    finally:
+        lib.ce_gemm_nt_tune(0)
+        assert lib.ce_gemm_set_dynamic_tiles(-1) == 0
+    for k in ("bf16", "bias_bf16", "dact", "gelu", "gelugrad"):
+        assert torch.equal(got[k], want[k]), k
+    assert _report("two heights colsum", got["colsum"].cpu(), want["colsum"].cpu())[1] < 1e-5      # (float atomics: order)
+    acc = (A.float() @ B.float().t()).cpu()
+    assert _report("two heights bf16", got["bf16"].float().cpu(), acc.to(torch.bfloat16).float())[1] < 1e-3
