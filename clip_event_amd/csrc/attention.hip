@@ -16,6 +16,7 @@
 // Backward: phase 1 per query strip recomputes P from the saved log-sum-exp, forms
 //   dS = scale * P (dP - delta), writes P^T / dS^T (bf16) to LDS and computes dQ^T = K^T dS^T;
 // phase 2 per 16-key tile computes dV^T = dO^T P and dK^T = Q^T dS from the LDS images.
+#include <map>
 #include <mutex>
 
 #include <type_traits>
@@ -607,8 +608,8 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ o, long ldo,
                                                                const bf16_t* __restrict__ dout, long lddo,
                                                                const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                               long lddq, float* __restrict__ bias_grad, int L, int H, int D,
-                                                               int causal, float scale) {
+                                                               long lddq, float* __restrict__ bias_grad, float* __restrict__ delta_out,
+                                                               int L, int H, int D, int causal, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW + 64 * 4];
     char* sK = smem;
     char* sV = smem + LB * ROW;
@@ -635,6 +636,9 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
         iok[s] = i[s] < L;
         q[s] = load_strip(base, ld, dob, lddo, ob, ldo, lse + ((long)b * H + h) * L, min(i[s], L - 1), g);
         lse2[s] = q[s].lse * 1.4426950408889634f;
+        // delta_i = sum_c dO[i][c] O[i][c], computed here once per query: handed to the dK / dV kernel (launched behind this one),
+        // whose every key block would otherwise recompute it for all L queries
+        if (delta_out && g == 0 && iok[s]) delta_out[((long)b * H + h) * L + i[s]] = q[s].dl;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -743,7 +747,8 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ o, long ldo,
                                                                 const bf16_t* __restrict__ dout, long lddo,
                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                                long lddq, float* __restrict__ bias_grad, int L, int H, int D,
+                                                                long lddq, float* __restrict__ bias_grad,
+                                                                const float* __restrict__ delta_in, int L, int H, int D,
                                                                 int causal, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW + (2 * LB + 128) * 4];
     char* sQ = smem;
@@ -756,7 +761,7 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
     const int kb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
     const bf16_t* base = qkv + (long)b * L * ld + h * HD;
     const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
-    const bf16_t* ob = o + (long)b * L * ldo + h * HD;
+    (void)o; (void)ldo;                                         // (delta arrives from the dQ kernel)
     bf16_t* dbase = dqkv + (long)b * L * lddq + h * HD;
     const float* lse_row = lse + ((long)b * H + h) * L;
     const int li = lane & 15, g = lane >> 4;
@@ -785,48 +790,28 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
     const int nqb = (L + LB - 1) / LB;
     const int qb0 = causal ? (kb * KB) / LB : 0;
     const float c2 = scale * 1.4426950408889634f;               // scale * log2(e)
-    const int il = wave * 16 + li;                              // the query this lane serves in the delta pass
-    auto strip_row = [&](int qb) { return min(qb * LB + il, L - 1); };
+    // per-query scalars of the block, one per thread: threads 0 .. 63 the log-sum-exp (stored in log2 units: p = exp2(s c - lse
+    // log2 e)), threads 64 .. 127 delta = sum_c dO O as the dQ kernel left it; requested one block ahead like Q and dO
+    const float* delta_row = delta_in + ((long)b * H + h) * L;
+    auto scalar_of = [&](int qb) __attribute__((always_inline)) -> float {
+        if (tid >= 2 * LB) return 0.f;
+        const int iq = min(qb * LB + (tid & (LB - 1)), L - 1);
+        return tid < LB ? lse_row[iq] * 1.4426950408889634f : delta_row[iq];
+    };
     BlockRegs nq = load_block(base, ld, qb0 * LB, L, tid), nd = load_block(dob, lddo, qb0 * LB, L, tid);
-    u32x4 no[2];
-    float nlse;
-    {
-        const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)strip_row(qb0) * ldo + g * 16);
-        no[0] = po[0]; no[1] = po[1];
-        nlse = lse_row[strip_row(qb0)];
-    }
+    float nsc = scalar_of(qb0);
     const bool keys_past_L = (kb + 1) * KB > L;                 // workgroup-uniform
     for (int qb = qb0; qb < nqb; ++qb) {
-        __syncthreads();                                       // previous block's Q / dO / delta consumed
+        __syncthreads();                                       // previous block's Q / dO / scalars consumed
         store_block(sQ, nq, tid);
         store_block(sDO, nd, tid);
-        const u32x4 o0 = no[0], o1 = no[1];
-        const float lse_i = nlse;
+        if (tid < 2 * LB) sLse[tid] = nsc;                      // (sDelta = sLse + LB)
         if (qb + 1 < nqb) {
             nq = load_block(base, ld, (qb + 1) * LB, L, tid);
             nd = load_block(dob, lddo, (qb + 1) * LB, L, tid);
-            const u32x4* po = reinterpret_cast<const u32x4*>(ob + (long)strip_row(qb + 1) * ldo + g * 16);
-            no[0] = po[0]; no[1] = po[1];
-            nlse = lse_row[strip_row(qb + 1)];
+            nsc = scalar_of(qb + 1);
         }
-        __syncthreads();                                       // Q / dO of this block visible
-        {   // delta_i = sum_c dO[i][c] O[i][c] for the block's 64 queries (4 lanes x 16 columns per query)
-            const u32x4 d0 = *reinterpret_cast<const u32x4*>(sDO + il * ROW + g * 32);
-            const u32x4 d1 = *reinterpret_cast<const u32x4*>(sDO + il * ROW + g * 32 + 16);
-            float dl = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                dl += bf_lo(d0[e]) * bf_lo(o0[e]) + bf_hi(d0[e]) * bf_hi(o0[e]);
-                dl += bf_lo(d1[e]) * bf_lo(o1[e]) + bf_hi(d1[e]) * bf_hi(o1[e]);
-            }
-            dl += __shfl_xor(dl, 16, 64);
-            dl += __shfl_xor(dl, 32, 64);
-            if (g == 0) {
-                sDelta[il] = dl;
-                sLse[il] = lse_i * 1.4426950408889634f;      // in log2 units: p = exp2(s c - lse log2 e)
-            }
-        }
-        __syncthreads();
+        __syncthreads();                                       // Q / dO / scalars of this block visible
         // one fma + v_exp_f32 per probability; dS without the softmax scale (applied once to the finished dK); the validity /
         // causal mask only in the blocks that need it: the last query block (padded queries repeat row L - 1 and must add
         // nothing to dK / dV), a key block that reaches past L (its column sums must stay zero) and under the causal mask
@@ -854,7 +839,11 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+#ifdef CE_ABL_NO_EXP
+                        float pv = __builtin_fmaf(sc[r], c2, -l4[r]);
+#else
                         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c2, -l4[r]));
+#endif
                         if constexpr (MASK) {
                             const int i = qb * LB + t * 16 + 4 * g + r;
                             const bool ok = jok[kt] && (i < L) && (!causal || j[kt] <= i);
@@ -869,6 +858,9 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
         if (need_mask) p_ds(std::true_type{});
         else p_ds(std::false_type{});
         // dV^T += dO^T P, dK^T += Q^T dS: contraction element jj of lane group g <-> query 32 s + 16 (jj>>2) + 4 g + (jj&3)
+#ifdef CE_ABL_NO_SECOND
+        for (int kt = 0; kt < NK; ++kt) for (int t = 0; t < 4; ++t) { av[kt][t] += p[kt][t]; ak[kt][t] += ds[kt][t]; }
+#else
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             bf16x8 pf[NK], sf[NK];
@@ -889,6 +881,7 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
                 }
             }
         }
+#endif
     }
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
@@ -927,6 +920,24 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
 }
 
 int tiles_for(int L) { return ((L + 31) / 32) * 2; }
+
+// Per-stream scratch of the long-sequence backward (delta, [B, H, L] floats: 1.2 MB at ViT-L/14@336, B = 32).  Grow-only; kernels
+// of one stream run in order, so consecutive calls on a stream may share it.  (hipMallocAsync / hipFreeAsync around the two
+// launches measured 25 us slower per call than this.)
+struct StreamScratch { float* p = nullptr; size_t cap = 0; };
+std::mutex g_scratch_mu;
+std::map<hipStream_t, StreamScratch> g_scratch;
+float* delta_scratch(hipStream_t s, size_t floats) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    StreamScratch& e = g_scratch[s];
+    if (e.cap < floats) {
+        if (e.p) hipFree(e.p);                       // (synchronises the device: nothing still reads the old buffer)
+        e.p = nullptr; e.cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&e.p), floats * sizeof(float)) != hipSuccess) return nullptr;
+        e.cap = floats;
+    }
+    return e.p;
+}
 
 }  // namespace
 
@@ -992,18 +1003,25 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
         static const int ns = getenv("CE_ATTN_NS") ? atoi(getenv("CE_ATTN_NS")) : 2;
         static const int nk = getenv("CE_ATTN_NK") ? atoi(getenv("CE_ATTN_NK")) : 1;
         const dim3 grid1((L + LB - 1) / LB, B * H), grid2((L + 2 * LB - 1) / (2 * LB), B * H);
+        // delta = rowsum(dO O), [B, H, L] floats: written by the dQ kernel, read by the dK / dV kernel behind it on the same stream;
+        // one grow-only scratch per stream, so two towers' backward passes on two streams never share it
+        float* delta = delta_scratch(sl, (size_t)B * H * L);
+        if (!delta) {
+            ce_set_error("ce_attention_bwd: no memory for %ld bytes of scratch", (long)B * H * L * 4);
+            return -12; /* -ENOMEM */
+        }
         if (ns == 1)
             hipLaunchKernelGGL(attn_bwd_long_dq_kernel<1>, grid1, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
         else
             hipLaunchKernelGGL(attn_bwd_long_dq_kernel<2>, grid2, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
         if (nk == 1)
             hipLaunchKernelGGL(attn_bwd_long_dkv_kernel<1>, grid1, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
         else
             hipLaunchKernelGGL(attn_bwd_long_dkv_kernel<2>, grid2, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
         CE_LAUNCH_CHECK();
         return 0;
     }

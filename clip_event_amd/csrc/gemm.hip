@@ -1987,6 +1987,11 @@ unsigned int* next_tile_queue(hipStream_t s) {
 // (ce_cu_hog) every such launch takes 1.6-1.75x as long.  A budget below 256 sizes the one-round and the persistent
 // grids for that many CUs, so that the rest may be taken.
 int g_cus = getenv("CE_GEMM_CUS") ? atoi(getenv("CE_GEMM_CUS")) : 256;
+// epilogues for which the persistent kernel is also built with two tile heights (launch_nt)
+constexpr bool nt_two_heights(int epi) {
+    return epi == CE_EPI_BIAS_GELU || epi == CE_EPI_GELUGRAD_BF16 || epi == CE_EPI_BIAS_BF16 || epi == CE_EPI_BF16 ||
+           epi == CE_EPI_BIAS_RESID_F16 || epi == CE_EPI_BIAS_RESID_F32;
+}
 inline int cu_budget() { return g_cus >= 32 && g_cus <= 256 ? g_cus : 256; }
 inline long nt256_cost(long tiles, int tm) { return ((tiles + cu_budget() - 1) / cu_budget()) * (28 + 10 * tm); }
 inline long nt32_cost(long tiles) {
@@ -2040,7 +2045,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
-        if constexpr (EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BF16) {
+        if constexpr (nt_two_heights(EPI)) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 5, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
@@ -2136,7 +2141,7 @@ int launch_nt(NTArgs a, hipStream_t stream) {
             // model; taken when it beats the best single height by >= 3 %.  12800 x 3072: 960 tiles of 160 rows = 3.75 rounds -> 3
             // rounds of 160 + one of 128.  CE_NT_MIXED=0 switches it off.
             g_last_tall = g_last_ts = 0;
-            constexpr bool mixed_epi = EPI == CE_EPI_BIAS_GELU || EPI == CE_EPI_GELUGRAD_BF16 || EPI == CE_EPI_BIAS_BF16 || EPI == CE_EPI_BF16;
+            constexpr bool mixed_epi = nt_two_heights(EPI);
             if constexpr (mixed_epi) {
                 static const int mixed = getenv("CE_NT_MIXED") ? atoi(getenv("CE_NT_MIXED")) : 1;
                 if (mixed && f == 0 && strip == 0 && a.tile_chunk == 0 && a.M >= 320) {
