@@ -2168,9 +2168,10 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                             if (rest <= 0) continue;
                             const long n_short = (rest + 32 * ts - 1) / (32 * ts);
                             const long c = span(n_tall, ts, n_short);
-                            if (c < best) { best = c; b_tall = n_tall; b_short = n_short; b_ts = ts; }
+                            if (c < best || (c == best && b_tall < 0)) { best = c; b_tall = n_tall; b_short = n_short; b_ts = ts; }
                         }
-                    if (b_tall > 0 && best * 100 <= uniform * 97) {
+                    static const int min_gain = getenv("CE_NT_MIXED_GAIN") ? atoi(getenv("CE_NT_MIXED_GAIN")) : 3;   // per cent
+                    if (b_tall > 0 && best * 100 <= uniform * (100 - min_gain)) {
                         a.tall_panels = (int)b_tall;
                         g_last_tall = (int)b_tall; g_last_ts = b_ts;
                         a.tiles_m = (int)(b_tall + b_short);

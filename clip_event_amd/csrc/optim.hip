@@ -46,6 +46,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// One element of clip + Adam.  Every kernel of this file updates through this function, with the contraction of a * b + c into
+// fused multiply-adds spelled out, so that the flat kernel, the tile kernel and the segment kernel give the same bits.
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float coef, float wd, float b1, float b2,
+                                          float lr_bc1, float bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+    g = g * coef;
+    if (wd != 0.f) g = __builtin_fmaf(p, wd, g);
+    m = __builtin_fmaf(m, b1, g * (1.0f - b1));
+    v = __builtin_fmaf(v, b2, (g * g) * (1.0f - b2));
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = __builtin_fmaf(-lr_bc1, m / denom, p);
+}
+__device__ __forceinline__ void adam_elem4(f32x4& p, f32x4 g, f32x4& m, f32x4& v, float coef, float wd, float b1, float b2,
+                                           float lr_bc1, float bc2_sqrt, float eps) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float pe = p[e], me = m[e], ve = v[e];
+        adam_elem(pe, g[e], me, ve, coef, wd, b1, b2, lr_bc1, bc2_sqrt, eps);
+        p[e] = pe; m[e] = me; v[e] = ve;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, bf16_t* __restrict__ p16, long n,
                                                    const float* __restrict__ sumsq, float max_norm, float lr, float b1,
@@ -73,15 +95,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const long i = u ? i1 : i0;
-                gv[u] = gv[u] * coef;
-                if (wd != 0.f) gv[u] += pv[u] * wd;
-                mv[u] = mv[u] * b1 + gv[u] * (1.0f - b1);
-                vv[u] = vv[u] * b2 + gv[u] * gv[u] * (1.0f - b2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float denom = sqrtf(vv[u][e]) / bc2_sqrt + eps;
-                    pv[u][e] -= (lr / bc1) * (mv[u][e] / denom);
-                }
+                adam_elem4(pv[u], gv[u], mv[u], vv[u], coef, wd, b1, b2, lr / bc1, bc2_sqrt, eps);
                 CE_ADAM_ST(pv[u], reinterpret_cast<f32x4*>(p + i));
                 if (p16) {
                     u32x2 pk = {pack_bf2(pv[u][0], pv[u][1]), pack_bf2(pv[u][2], pv[u][3])};
@@ -94,14 +108,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             for (int u = 0; u < 2; ++u) {
                 const long ib = u ? i1 : i0;
                 for (long k = ib; k < n && k < ib + 4; ++k) {
-                    float gk = g[k] * coef;
-                    if (wd != 0.f) gk += p[k] * wd;
-                    const float mk = m[k] * b1 + gk * (1.0f - b1);
-                    const float vk = v[k] * b2 + gk * gk * (1.0f - b2);
-                    p[k] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+                    float pk = p[k], mk = m[k], vk = v[k];
+                    adam_elem(pk, g[k], mk, vk, coef, wd, b1, b2, lr / bc1, bc2_sqrt, eps);
+                    p[k] = pk;
                     m[k] = mk;
                     v[k] = vk;
-                    if (p16) p16[k] = f2bf(p[k]);
+                    if (p16) p16[k] = f2bf(pk);
                 }
             }
         }
@@ -175,6 +187,98 @@ __global__ __launch_bounds__(256) void multi_transpose_kernel(const ce_transpose
     }
 }
 
+// clip + Adam over a table of bf16-mirrored MATRICES, one 64 x 64 tile per workgroup: the update of `adam_kernel` element for
+// element, and with it BOTH operand copies of the new weights -- the row-major bf16 mirror and, through an LDS transpose of the
+// tile, the W^T copy the input-gradient GEMMs read (`job.dst`, [cols][rows]) -- so that no separate transpose pass re-reads the
+// mirror (`multi_transpose_kernel`: 0.17 GB read + a launch beside the next forward's first kernels).  `job.src` points into the
+// flat mirror `p16`: its offset there is the matrix's offset in every flat buffer.  rows, cols multiples of 8.
+__global__ __launch_bounds__(256) void adam_tiles_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, bf16_t* __restrict__ p16,
+                                                         const ce_transpose_job* __restrict__ jobs, int njobs,
+                                                         const float* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2_sqrt) {
+    __shared__ bf16_t tile[64][66];
+    float coef = 1.0f;
+    if (sumsq) coef = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    int j = 0;
+    const int b = blockIdx.x;
+    while (j + 1 < njobs && b >= jobs[j + 1].tile_start) ++j;      // block-uniform
+    const ce_transpose_job job = jobs[j];
+    const int t = b - job.tile_start;
+    const int tiles_c = (job.cols + 63) / 64;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const long off = reinterpret_cast<const bf16_t*>(job.src) - p16;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(job.dst);
+    // 64 rows x 16 four-element chunks; all sixteen loads of a thread in flight before the first use
+    f32x4 pv[4], gv[4], mv[4], vv[4];
+    bool ok[4];
+    long at[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int r = idx >> 4, ch = idx & 15;
+        ok[k] = r0 + r < job.rows && c0 + ch * 4 < job.cols;
+        at[k] = off + (long)(r0 + r) * job.cols + c0 + ch * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        pv[k] = z; gv[k] = z; mv[k] = z; vv[k] = z;
+        if (ok[k]) {
+            pv[k] = CE_ADAM_LD(reinterpret_cast<f32x4*>(p + at[k]));
+            gv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + at[k]));
+            mv[k] = CE_ADAM_LD(reinterpret_cast<f32x4*>(m + at[k]));
+            vv[k] = CE_ADAM_LD(reinterpret_cast<f32x4*>(v + at[k]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int r = idx >> 4, ch = idx & 15;
+        adam_elem4(pv[k], gv[k], mv[k], vv[k], coef, wd, b1, b2, lr / bc1, bc2_sqrt, eps);
+        const u32x2 pk = {pack_bf2(pv[k][0], pv[k][1]), pack_bf2(pv[k][2], pv[k][3])};
+        uint32_t* trow = reinterpret_cast<uint32_t*>(&tile[r][ch * 4]);
+        trow[0] = pk[0]; trow[1] = pk[1];
+        if (ok[k]) {
+            CE_ADAM_ST(pv[k], reinterpret_cast<f32x4*>(p + at[k]));
+            *reinterpret_cast<u32x2*>(p16 + at[k]) = pk;
+            CE_ADAM_ST(mv[k], reinterpret_cast<f32x4*>(m + at[k]));
+            CE_ADAM_ST(vv[k], reinterpret_cast<f32x4*>(v + at[k]));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = threadIdx.x + k * 256;                 // 64 output rows (source columns) x 8 chunks of 8 source rows
+        const int c = idx >> 3, ch = idx & 7;
+        if (c0 + c < job.cols && r0 + ch * 8 < job.rows) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = (uint32_t)tile[ch * 8 + 2 * e][c] | ((uint32_t)tile[ch * 8 + 2 * e + 1][c] << 16);
+            *reinterpret_cast<u32x4*>(dst + (long)(c0 + c) * job.rows + r0 + ch * 8) = u32x4{w[0], w[1], w[2], w[3]};
+        }
+    }
+}
+
+// the same update over a table of [lo, hi) chunks of the flat buffers (everything that is not one of the matrices above)
+__global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, bf16_t* __restrict__ p16, const long* __restrict__ table,
+                                                            const float* __restrict__ sumsq, float max_norm, float lr, float b1, float b2,
+                                                            float eps, float wd, float bc1, float bc2_sqrt) {
+    float coef = 1.0f;
+    if (sumsq) coef = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    const long lo = table[2 * blockIdx.x], hi = table[2 * blockIdx.x + 1];
+    for (long i = lo + threadIdx.x * 4; i + 3 < hi; i += 1024) {
+        f32x4 pv = CE_ADAM_LD(reinterpret_cast<f32x4*>(p + i));
+        f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+        f32x4 mv = CE_ADAM_LD(reinterpret_cast<f32x4*>(m + i));
+        f32x4 vv = CE_ADAM_LD(reinterpret_cast<f32x4*>(v + i));
+        adam_elem4(pv, gv, mv, vv, coef, wd, b1, b2, lr / bc1, bc2_sqrt, eps);
+        CE_ADAM_ST(pv, reinterpret_cast<f32x4*>(p + i));
+        if (p16) *reinterpret_cast<u32x2*>(p16 + i) = u32x2{pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
+        CE_ADAM_ST(mv, reinterpret_cast<f32x4*>(m + i));
+        CE_ADAM_ST(vv, reinterpret_cast<f32x4*>(v + i));
+    }
+}
+
 }  // namespace
 
 extern "C" int ce_multi_transpose_bf16(const ce_transpose_job* jobs_device, int njobs, int total_tiles, void* stream) {
@@ -220,6 +324,24 @@ extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, void* 
     if (g_adam_grid > 0 && blocks > g_adam_grid) blocks = g_adam_grid;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, sumsq,
                        max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+    CE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ce_adam_step_tiles(float* p, const float* g, float* m, float* v, void* p_bf16, const ce_transpose_job* jobs_device,
+                                  int njobs, int total_tiles, const long* segments_device, int nsegments, const float* sumsq,
+                                  float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                  void* stream) {
+    CE_CHECK_ARG(p && g && m && v && p_bf16 && step >= 1, "ce_adam_step_tiles: null buffer or step < 1");
+    CE_CHECK_ARG((jobs_device && njobs > 0 && total_tiles > 0) || (segments_device && nsegments > 0), "ce_adam_step_tiles: nothing to update");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    if (njobs > 0)
+        hipLaunchKernelGGL(adam_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+                           jobs_device, njobs, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+    if (nsegments > 0)
+        hipLaunchKernelGGL(adam_segments_kernel, dim3((unsigned)nsegments), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+                           segments_device, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
     CE_LAUNCH_CHECK();
     return 0;
 }

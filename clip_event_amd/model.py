@@ -238,7 +238,7 @@ class CLIP(nn.Module):
     # rebuilt lazily by _prepare(); only the parameters and the plain attributes travel --------------------------
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
-                "_tjobs_bwd", "_tjobs_split", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
+                "_tjobs_bwd", "_tjobs_split", "_adam_tiles_ok", "_wt_fresh", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
                 "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "_step_events", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_zero_tables", "_first_touch", "_pending_text", "_in_fork")
 
     def __getstate__(self):
@@ -579,6 +579,11 @@ class CLIP(nn.Module):
         self._tjobs = table(["visual.proj", "text_projection"])
         self._tjobs_split = (table(["visual.proj"]), table(["text_projection"]))
         self._tjobs_bwd = table(gemm_names)
+        # fused Adam in tiles (optim.FusedAdam.step -> ce_adam_step_tiles) leaves these W^T copies behind itself: possible when the
+        # table is exactly the block weights (whose complement is the zero-fill chunk table) and every matrix has 8-multiples
+        self._adam_tiles_ok = (set(gemm_names) == {n for n in self._pmap if self._is_block_weight(n)} and
+                               all(self._pmap[n].shape[0] % 8 == 0 and self._pmap[n].shape[1] % 8 == 0 for n in gemm_names))
+        self._wt_fresh = False            # True when the fused Adam has just written the blocks' W^T copies as well
         self._wt_event = None
         self._mirror_fresh = False        # True when the Adam kernel has just written _flat16 ...
         self._mirror_versions = None      # ... from masters at these parameter versions
@@ -698,7 +703,9 @@ class CLIP(nn.Module):
             with torch.cuda.stream(self._side_streams[1]):      # behind the update, ahead of the text forward
                 check(cl.ce_multi_transpose_bf16(ptr(xj), c_int(xn), c_int(xt), stream()), "ce_multi_transpose_bf16(text)")
         tj, tn_, tt = self._tjobs_bwd
-        if getattr(self, "tower_streams", True) and not self.fp8 and os.environ.get("CE_ASYNC_TRANSPOSE", "1") != "0":
+        if self._mirror_fresh and vers == self._mirror_versions and getattr(self, "_wt_fresh", False):
+            pass                          # the fused Adam wrote the blocks' W^T copies with the update (ce_adam_step_tiles)
+        elif getattr(self, "tower_streams", True) and not self.fp8 and os.environ.get("CE_ASYNC_TRANSPOSE", "1") != "0":
             # the blocks' W^T copies (0.15 ms of pure copying) on a third stream, beside the forward that is about to be
             # enqueued; every tower backward, and whoever rewrites the bf16 mirror next, waits for the event
             cur = torch.cuda.current_stream()
@@ -721,6 +728,7 @@ class CLIP(nn.Module):
             check(cl.ce_cast_transpose(ptr(self._pmap["visual.conv1.weight"]), ptr(self._conv_pad), c_long(self._kp), None,
                                        c_long(0), c_int(self.vision_width), c_int(self._kp_real), s), "ce_cast_transpose(conv1)")
         self._mirror_fresh = False
+        self._wt_fresh = False
         self._versions = vers
         self._fp8_fresh = False
         if self.fp8:
@@ -732,11 +740,12 @@ class CLIP(nn.Module):
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def mark_operands_stale(self, mirror_fresh: bool = False):
+    def mark_operands_stale(self, mirror_fresh: bool = False, wt_fresh: bool = False):
         """``mirror_fresh``: the caller (fused Adam) has already written the bf16 mirror of the new masters,
-        only the transposed copies need rebuilding."""
+        only the transposed copies need rebuilding; ``wt_fresh``: it has written the blocks' W^T copies too."""
         self._versions = None
         self._mirror_fresh = mirror_fresh
+        self._wt_fresh = bool(mirror_fresh and wt_fresh)
         self._mirror_versions = tuple(self._pmap[n]._version for n in self._cast_list) if mirror_fresh else None
 
     def join_updates(self):

@@ -143,6 +143,19 @@ class FusedAdam(torch.optim.Optimizer):
                 ev = torch.cuda.Event()
                 ev.record(side[1])
             m._pending_text = ev
+        elif getattr(m, "_adam_tiles_ok", False) and os.environ.get("CE_ADAM_TILES", "1") != "0":
+            # the block weights tile by tile, which also writes their W^T operand copies (no transpose pass at the start of the
+            # next step); everything else by the chunk table of the first-touch zero-fill (= the complement of the block weights)
+            tj, tn_, tt = m._tjobs_bwd
+            seg = m._zero_tables_for()[0]
+            check(lib().ce_adam_step_tiles(ptr(m._flat), ptr(m._flat_grad), ptr(self.m), ptr(self.v), ptr(m._flat16), ptr(tj), c_int(tn_),
+                                           c_int(tt), ptr(seg), c_int(seg.shape[0]), ptr(sumsq), c_float(self.max_norm or 0.0), c_float(lr),
+                                           c_float(self.betas[0]), c_float(self.betas[1]), c_float(self.eps), c_float(self.weight_decay),
+                                           c_int(self.step_count), s), "ce_adam_step_tiles")
+            m.mark_operands_stale(mirror_fresh=True, wt_fresh=True)
+            if self.sat_poll_every and self.step_count % self.sat_poll_every == 0 and hasattr(m, "poll_stream16_saturation"):
+                m.poll_stream16_saturation()
+            return
         else:
             adam(0, n, s)
         m.mark_operands_stale(mirror_fresh=True)

@@ -1114,3 +1114,47 @@ def test_deferred_text_update_equals_the_one_launch_update(monkeypatch):
     rel, noise = float((m1._flat - m0._flat).norm() / m0._flat.norm()), float((m0b._flat - m0._flat).norm() / m0._flat.norm())
     print(f"after a hand-driven step: rel-l2 {rel:.3e} (noise {noise:.3e})")
     assert rel < 1e-4
+
+
+def test_fused_adam_in_tiles_equals_the_flat_kernel(monkeypatch):
+    """`ce_adam_step_tiles` (default): the block weights are updated tile by tile, which also writes their W^T operand copies, the
+    rest through the chunk table of the first-touch zero-fill.  Same arithmetic element for element: masters, both moments and the
+    bf16 mirror are BIT-identical to the flat kernel's, every W^T copy is the transpose of its mirror, no element is updated twice
+    or skipped (a second step from identical state), and the next forward needs no transpose pass of the blocks."""
+    from oracle import clip_oracle as O
+    from clip_event_amd import synthetic as S
+    from clip_event_amd.optim import FusedAdam
+    cfg = O.ClipConfig(64, 64, 3, 192, 32, 20, 512, 128, 2, 3)
+    out = {}
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("CE_ADAM_TILES", tiles)
+        m, _ = _mk(cfg, 5)
+        # (max_norm far above the norm: the clip coefficient is exactly 1 whatever order the norm's float atomics arrived in)
+        opt = FusedAdam(m, lr=1e-3, max_norm=1e9, weight_decay=0.01)
+        opt.zero_grad()
+        assert m._adam_tiles_ok
+        g = torch.Generator(device="cpu").manual_seed(3)
+        for it in range(2):
+            m._flat_grad.copy_(torch.randn(m._flat_grad.numel(), generator=g).to(DEV) * 0.05)
+            opt.step()
+            assert m._wt_fresh == (tiles == "1") and m._mirror_fresh
+        torch.cuda.synchronize()
+        for n in m._pmap:
+            if m._is_block_weight(n):
+                if tiles == "1":
+                    assert torch.equal(m._w16t[n], m._w16[n].t().contiguous()), n
+        img = S.synthetic_images(2, cfg.image_resolution, seed=1).to(DEV)
+        txt = S.synthetic_tokens(2, cfg.context_length, cfg.vocab_size, seed=2, min_len=2).to(DEV)
+        with torch.no_grad():
+            li, lt = m(img, txt)                       # refresh_operands: (tiles) nothing to transpose but the two projections
+        assert not m._wt_fresh
+        for n in m._pmap:
+            if m._is_block_weight(n):
+                assert torch.equal(m._w16t[n], m._w16[n].t().contiguous()), n
+        live = torch.zeros(m._flat.numel(), dtype=torch.bool, device=DEV)          # (the flat kernel also "updates" the layout's padding)
+        for n, p_ in m._pmap.items():
+            live[m._offsets[n]: m._offsets[n] + p_.numel()] = True
+        out[tiles] = (m._flat[live].clone(), opt.m[live].clone(), opt.v[live].clone(), m._flat16[live].clone(), li.clone())
+    for i, what in enumerate(("masters", "exp_avg", "exp_avg_sq", "bf16 mirror", "logits")):
+        a, b = out["1"][i], out["0"][i]
+        assert torch.equal(a, b), (what, int((a != b).sum()), float((a.float() - b.float()).abs().max()))
