@@ -239,7 +239,7 @@ class CLIP(nn.Module):
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
                 "_tjobs_bwd", "_tjobs_split", "_adam_tiles_ok", "_wt_fresh", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
-                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "_step_events", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_zero_tables", "_first_touch", "_pending_text", "_in_fork")
+                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "_step_events", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_zero_tables", "_adam_segs", "_first_touch", "_pending_text", "_in_fork")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -443,6 +443,17 @@ class CLIP(nn.Module):
             as_table = lambda rows: torch.tensor(rows, dtype=torch.int64).reshape(-1, 2).to(dev)
             self._zero_tables = (as_table(chunks), as_table([c for c in chunks if c[0] < t0]), as_table([c for c in chunks if c[0] >= t0]))
         return self._zero_tables
+
+    def _adam_segment_table(self):
+        """The zero-fill chunk table (= every element outside the block weights) cut into pieces of at most 2048 elements: one
+        workgroup of ``ce_adam_step_tiles``' segment kernel each."""
+        if getattr(self, "_adam_segs", None) is None:
+            rows = []
+            for lo, hi in self._zero_tables_for()[0].tolist():
+                for c in range(lo, hi, 2048):
+                    rows.append((c, min(c + 2048, hi)))
+            self._adam_segs = torch.tensor(rows, dtype=torch.int64).reshape(-1, 2).to(self._flat_grad.device)
+        return self._adam_segs
 
     def _zero_segments(self, table):
         if table.shape[0]:

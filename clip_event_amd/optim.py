@@ -147,7 +147,7 @@ class FusedAdam(torch.optim.Optimizer):
             # the block weights tile by tile, which also writes their W^T operand copies (no transpose pass at the start of the
             # next step); everything else by the chunk table of the first-touch zero-fill (= the complement of the block weights)
             tj, tn_, tt = m._tjobs_bwd
-            seg = m._zero_tables_for()[0]
+            seg = m._adam_segment_table()
             check(lib().ce_adam_step_tiles(ptr(m._flat), ptr(m._flat_grad), ptr(self.m), ptr(self.v), ptr(m._flat16), ptr(tj), c_int(tn_),
                                            c_int(tt), ptr(seg), c_int(seg.shape[0]), ptr(sumsq), c_float(self.max_norm or 0.0), c_float(lr),
                                            c_float(self.betas[0]), c_float(self.betas[1]), c_float(self.eps), c_float(self.weight_decay),

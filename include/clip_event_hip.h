@@ -317,7 +317,7 @@ int ce_multi_transpose_bf16(const ce_transpose_job* jobs_device, int njobs, int 
 /* clip + Adam (ce_adam_step's arithmetic, element for element) in a form that also leaves the TRANSPOSED bf16 copies of the weight
  * matrices behind: `jobs` lists matrices whose `src` points into the flat bf16 mirror `p_bf16` (same offset in p / g / m / v) and whose
  * `dst` receives W^T ([cols][rows]; rows, cols multiples of 8); one 64 x 64 tile per workgroup, `total_tiles` as for
- * ce_multi_transpose_bf16.  `segments` = [lo, hi) element ranges (multiples of 4, at most 2^16 long) of everything that is not one
+ * ce_multi_transpose_bf16.  `segments` = [lo, hi) element ranges (multiples of 4, at most 2048 long: one workgroup each) of everything that is not one
  * of those matrices.  Replaces ce_adam_step + the ce_multi_transpose_bf16 pass of the next step (engine.py:87-95). */
 int ce_adam_step_tiles(float* p, const float* g, float* m, float* v, void* p_bf16, const ce_transpose_job* jobs_device, int njobs,
                        int total_tiles, const long* segments_device, int nsegments, const float* sumsq, float max_norm, float lr,

@@ -1100,9 +1100,11 @@ def test_deferred_text_update_equals_the_one_launch_update(monkeypatch):
             a, b, c = get(m1, o1)[pick], get(m0, o0)[pick], get(m0b, o0b)[pick]
             rel, noise = float((a - b).norm() / b.norm()), float((c - b).norm() / b.norm())
             print(f"deferred vs one-launch update, {where}, {what}: rel-l2 {rel:.3e} (two one-launch runs: {noise:.3e})")
-            # (moments: once two runs differ in a last bit, bf16 roundings downstream flip and the next gradients differ at the bf16 level)
-            # (bf16 mirror: one flipped rounding of a master is a bf16 ulp, 4e-3 of that element)
-            assert rel < (1e-4 if what == "masters" else 3.0 * noise + (1e-4 if what == "bf16 mirror" else 2e-3)), (where, what)
+            # Fixed bounds from what two runs of ONE mode show when their atomics happen to differ (they do not always: the yardstick
+            # printed beside is anything from 3e-9 to the figures here): masters 1e-5, mirror 1.5e-4 (one flipped rounding of a master
+            # is a bf16 ulp), moments 1e-2 (once two runs differ in a last bit, bf16 roundings downstream flip and the next gradients
+            # differ at the bf16 level).  An update that raced with its readers is off by O(1) in the text tower.
+            assert rel < {"masters": 1e-4, "bf16 mirror": 6e-4, "exp_avg": 5e-2, "exp_avg_sq": 5e-2}[what], (where, what)
     # a step driven by hand after train_step (plain zero_grad / backward / step) still sees complete text gradients
     crit = CriterionContrastive("ce")
     for m, o in ((m1, o1), (m0, o0)):

@@ -2,7 +2,7 @@
 """GPU busy / idle time from a rocprofv3 kernel trace of the default (two-stream) bench:
     rocprofv3 --kernel-trace -d OUT --output-format csv -- python3 bench.py --no-cpu-baseline --no-roofline --no-dense-compare --steps 10 --warmup 3
     python3 tools/trace_idle.py OUT
-Prints, for the last 8 steps (delimited by adam_kernel launches): wall time per step, the time during which at least one
+Prints, for the last 8 steps (delimited by the last kernel of the optimiser step: adam_segments_kernel, or adam_kernel with CE_ADAM_TILES=0): wall time per step, the time during which at least one
 kernel was running, the time with two or more running, and the largest gaps with the kernels around them."""
 import csv, glob, os, sys
 import re
@@ -22,7 +22,7 @@ def short(n):
     if m:
         return f"torch:{m.group(1)[:24]}:{m.group(2)[:16]}"
     return n.split("(")[0][:44]
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+adam = [i for i, r in enumerate(rows) if "adam_segments_kernel" in r[2]] or [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
 if len(adam) < 10:
     sys.exit("not enough steps in the trace")
 lo, hi = adam[-9], adam[-1]
