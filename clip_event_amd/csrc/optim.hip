@@ -320,14 +320,6 @@ extern "C" int ce_sumsq(const float* g, long n, float* out, void* stream) {
     return 0;
 }
 
-static long g_adam_grid = 0;
-// workgroups of the NEXT ce_adam_step launches (0: the default, CE_ADAM_BLOCKS): an update that runs beside other kernels
-// can be confined to a few CUs' worth of workgroups
-extern "C" int ce_adam_set_grid(long blocks) {
-    g_adam_grid = blocks > 0 ? blocks : 0;
-    return 0;
-}
-
 extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* sumsq,
                             float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                             void* stream) {
@@ -337,7 +329,6 @@ extern "C" int ce_adam_step(float* p, const float* g, float* m, float* v, void* 
     long blocks = (n + 2047) / 2048;
     static const long cap = getenv("CE_ADAM_BLOCKS") ? atol(getenv("CE_ADAM_BLOCKS")) : 4096;
     if (blocks > cap) blocks = cap;
-    if (g_adam_grid > 0 && blocks > g_adam_grid) blocks = g_adam_grid;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, sumsq,
                        max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
     CE_LAUNCH_CHECK();

@@ -19,7 +19,6 @@ from . import distributed as D
 from .functional import (attach_lengths, fused_contrastive_losses, fused_head_ok, logits_from_features, small_contrastive_losses,
                          small_head_ok, tokens_to_device)
 from .losses import CriterionAlignment, CriterionContrastive
-from .optim import FusedAdam
 
 
 def _unwrap(model):
@@ -240,9 +239,6 @@ def train_step(model, criterion, optimizer, image, text, labels_per_image, label
         model._settle_first_touch()    # a tower without a backward pass in this step: its weight gradients are zero
     if grad_sync is not None:
         grad_sync.finish()             # no-op when the autograd final callback has already run it
-    if isinstance(optimizer, FusedAdam):
-        optimizer.step(defer_text=True)       # clip + Adam; the text tower's share beside the next step's image forward
-    else:
-        optimizer.step()                                                                   # clip + Adam
+    optimizer.step()                                                                       # clip + Adam
     _mark_step_end(model)
     return loss_dict

@@ -238,8 +238,8 @@ class CLIP(nn.Module):
     # rebuilt lazily by _prepare(); only the parameters and the plain attributes travel --------------------------
     _RUNTIME = ("_flat", "_flat_grad", "_flat16", "_offsets", "_ranges", "_layer_end", "_pmap", "_pool", "_trigger",
                 "_versions", "_w16", "_w16t", "_kp", "_kp_real", "_conv_pad", "_conv_gpad", "_cast_list", "_tjobs",
-                "_tjobs_bwd", "_tjobs_split", "_adam_tiles_ok", "_wt_fresh", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
-                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "_step_events", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_zero_tables", "_adam_segs", "_first_touch", "_pending_text", "_in_fork")
+                "_tjobs_bwd", "_adam_tiles_ok", "_wt_fresh", "_wt_event", "_aux_stream", "_mirror_fresh", "_mirror_versions", "_vdesc", "_tdesc", "_vblocks", "_tblocks",
+                "_side_streams", "_main_stream", "_pack_cache", "_cls_rows", "_sat", "_sat_poll", "_step_events", "grad_sync", "_w8", "_fp8_fresh", "_zero_table", "_zero_tables", "_adam_segs", "_first_touch")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -422,8 +422,8 @@ class CLIP(nn.Module):
     def _is_block_weight(self, name: str) -> bool:
         return "resblocks." in name and name.endswith(self._BLOCK_WEIGHTS)
 
-    def _zero_tables_for(self):
-        """Chunk tables of the gradient segments a first-touch step zero-fills: (everything, head + image tower, text tower)."""
+    def _zero_table_for(self):
+        """Chunk table of the gradient segments a first-touch step zero-fills: every element outside the block weights."""
         if getattr(self, "_zero_tables", None) is None:
             keep = sorted((self._offsets[n], self._offsets[n] + self._pmap[n].numel()) for n in self._pmap if self._is_block_weight(n))
             segs, pos = [], 0
@@ -433,15 +433,11 @@ class CLIP(nn.Module):
                 pos = (hi + 63) // 64 * 64          # the padding behind a tensor is never read
             if pos < self._flat_grad.numel():
                 segs.append((pos, self._flat_grad.numel()))
-            t0 = self._ranges["text"][0]
             chunks = []
             for lo, hi in segs:
-                for a, b in ((lo, min(hi, t0)), (max(lo, t0), hi)):     # no chunk straddles the text tower's start
-                    for c in range(a, b, 1 << 16):
-                        chunks.append((c, min(c + (1 << 16), b)))
-            dev = self._flat_grad.device
-            as_table = lambda rows: torch.tensor(rows, dtype=torch.int64).reshape(-1, 2).to(dev)
-            self._zero_tables = (as_table(chunks), as_table([c for c in chunks if c[0] < t0]), as_table([c for c in chunks if c[0] >= t0]))
+                for c in range(lo, hi, 1 << 16):
+                    chunks.append((c, min(c + (1 << 16), hi)))
+            self._zero_tables = torch.tensor(chunks, dtype=torch.int64).reshape(-1, 2).to(self._flat_grad.device)
         return self._zero_tables
 
     def _adam_segment_table(self):
@@ -449,7 +445,7 @@ class CLIP(nn.Module):
         workgroup of ``ce_adam_step_tiles``' segment kernel each."""
         if getattr(self, "_adam_segs", None) is None:
             rows = []
-            for lo, hi in self._zero_tables_for()[0].tolist():
+            for lo, hi in self._zero_table_for().tolist():
                 for c in range(lo, hi, 2048):
                     rows.append((c, min(c + 2048, hi)))
             self._adam_segs = torch.tensor(rows, dtype=torch.int64).reshape(-1, 2).to(self._flat_grad.device)
@@ -461,20 +457,8 @@ class CLIP(nn.Module):
 
     def zero_grad_first_touch(self):
         if self._flat_grad is None or os.environ.get("CE_WGRAD_FIRST_TOUCH", "1") == "0":
-            self.join_updates()
             return self.zero_grad()
-        everything, main_part, text_part = self._zero_tables_for()
-        if getattr(self, "_pending_text", None) is None:
-            self._zero_segments(everything)
-        else:
-            # a deferred text-tower update (optim.FusedAdam.step(defer_text=True)) is still reading the text gradients on the text
-            # tower's stream: their zero-fill queues behind it there (ahead of the text tower's next forward and backward)
-            self._zero_segments(main_part)
-            with torch.cuda.stream(self._side_streams[1]):
-                self._zero_segments(text_part)
-                ev = torch.cuda.Event()
-                ev.record(self._side_streams[1])
-            self._pending_text = ev          # whoever joins the update also waits for this fill
+        self._zero_segments(self._zero_table_for())
         self._attach_grads_fast()
         self._first_touch = {"visual", "text"}
 
@@ -491,7 +475,6 @@ class CLIP(nn.Module):
         self._first_touch = set()
 
     def zero_grad(self, set_to_none: bool = False):  # noqa: D401 - nn.Module API
-        self.join_updates()
         self._first_touch = set()
         if self._flat_grad is not None and not set_to_none:
             self._flat_grad.zero_()
@@ -588,7 +571,6 @@ class CLIP(nn.Module):
         # two tables: the feature projections' W^T are FORWARD operands; the blocks' W^T are read by the backward only
         # (input-gradient GEMMs), so their rebuild can run beside the next forward (refresh_operands)
         self._tjobs = table(["visual.proj", "text_projection"])
-        self._tjobs_split = (table(["visual.proj"]), table(["text_projection"]))
         self._tjobs_bwd = table(gemm_names)
         # fused Adam in tiles (optim.FusedAdam.step -> ce_adam_step_tiles) leaves these W^T copies behind itself: possible when the
         # table is exactly the block weights (whose complement is the zero-fill chunk table) and every matrix has 8-multiples
@@ -698,21 +680,10 @@ class CLIP(nn.Module):
         # master has moved since (load_state_dict, a stock optimiser step, an EMA swap), cast again
         if not (self._mirror_fresh and vers == self._mirror_versions):
             self.wait_transposes()        # an earlier asynchronous rebuild may still be reading the mirror
-            if getattr(self, "_pending_text", None) is not None:      # ... and so may a deferred text-tower update
-                torch.cuda.current_stream().wait_event(self._pending_text)
-                self._pending_text = None
             # masters changed outside the fused optimiser: rebuild the whole bf16 mirror (one launch)
             check(cl.ce_cast_bf16(ptr(self._flat), ptr(self._flat16), c_long(self._flat.numel()), s), "ce_cast_bf16")
-        pending = getattr(self, "_pending_text", None)      # a deferred text-tower update still running on the text stream
-        if pending is None:
-            tj, tn_, tt = self._tjobs
-            check(cl.ce_multi_transpose_bf16(ptr(tj), c_int(tn_), c_int(tt), s), "ce_multi_transpose_bf16")
-        else:
-            # (only encode_both gets here with the update pending: everyone else has joined it in _ready)
-            (vj, vn, vt), (xj, xn, xt) = self._tjobs_split
-            check(cl.ce_multi_transpose_bf16(ptr(vj), c_int(vn), c_int(vt), s), "ce_multi_transpose_bf16")
-            with torch.cuda.stream(self._side_streams[1]):      # behind the update, ahead of the text forward
-                check(cl.ce_multi_transpose_bf16(ptr(xj), c_int(xn), c_int(xt), stream()), "ce_multi_transpose_bf16(text)")
+        tj, tn_, tt = self._tjobs
+        check(cl.ce_multi_transpose_bf16(ptr(tj), c_int(tn_), c_int(tt), s), "ce_multi_transpose_bf16")
         tj, tn_, tt = self._tjobs_bwd
         if self._mirror_fresh and vers == self._mirror_versions and getattr(self, "_wt_fresh", False):
             pass                          # the fused Adam wrote the blocks' W^T copies with the update (ce_adam_step_tiles)
@@ -723,17 +694,12 @@ class CLIP(nn.Module):
             if getattr(self, "_aux_stream", None) is None or self._aux_stream.device != self._flat.device:
                 self._aux_stream = torch.cuda.Stream(device=self._flat.device)
             self._aux_stream.wait_stream(cur)
-            if pending is not None:
-                self._aux_stream.wait_event(pending)
             with torch.cuda.stream(self._aux_stream):
                 check(cl.ce_multi_transpose_bf16(ptr(tj), c_int(tn_), c_int(tt), stream()), "ce_multi_transpose_bf16(blocks)")
                 self._wt_event = torch.cuda.Event()
                 self._wt_event.record(self._aux_stream)
         else:
             self.wait_transposes()
-            if pending is not None:
-                torch.cuda.current_stream().wait_event(pending)
-                self._pending_text = None
             check(cl.ce_multi_transpose_bf16(ptr(tj), c_int(tn_), c_int(tt), s), "ce_multi_transpose_bf16(blocks)")
         if self._conv_pad is not None:
             check(cl.ce_cast_transpose(ptr(self._pmap["visual.conv1.weight"]), ptr(self._conv_pad), c_long(self._kp), None,
@@ -759,33 +725,9 @@ class CLIP(nn.Module):
         self._wt_fresh = bool(mirror_fresh and wt_fresh)
         self._mirror_versions = tuple(self._pmap[n]._version for n in self._cast_list) if mirror_fresh else None
 
-    def join_updates(self):
-        """Order the current stream behind a deferred text-tower update (``optim.FusedAdam.step(defer_text=True)``, which
-        ``engine.train_step`` uses: the text tower's share of clip + Adam runs on the text tower's stream beside the next step's
-        image forward).  Every method of the model and of the optimiser calls this; code that reads ``transformer.*`` /
-        ``token_embedding`` / ``positional_embedding`` / ``ln_final`` / ``text_projection`` tensors DIRECTLY between two
-        ``train_step`` calls calls it first."""
-        ev = getattr(self, "_pending_text", None)
-        if ev is not None and not getattr(self, "_in_fork", False):
-            torch.cuda.current_stream().wait_event(ev)
-            self._pending_text = None
-
-    def state_dict(self, *args, **kwargs):
-        self.join_updates()
-        return super().state_dict(*args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self.join_updates()
-        return super().load_state_dict(*args, **kwargs)
-
-    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float() ...
-        self.join_updates()
-        return super()._apply(fn, *args, **kwargs)
-
     def _ready(self):
         if not self._flat_ok():
             self._prepare()
-        self.join_updates()
         dev = self._flat.device
         if torch.cuda.current_device() != dev.index:
             # launches go to the CURRENT device's stream: running a model that lives on another GPU would fault
@@ -831,15 +773,7 @@ class CLIP(nn.Module):
         ``tower_streams`` (default) they run on two HIP streams: the ramp-up / tail of every kernel of one
         tower (and the CUs a ragged tile grid leaves idle) is filled by the other tower's kernels.  The
         autograd engine replays each tower's backward on its forward stream, so the backward overlaps too."""
-        if not getattr(self, "tower_streams", True) or getattr(self, "_side_streams", None) is None or self.fp8:
-            self._ready()
-        else:
-            # a deferred text-tower update is joined by the text stream's own order, not by this stream: the image tower starts now
-            self._in_fork = True
-            try:
-                self._ready()
-            finally:
-                self._in_fork = False
+        self._ready()
         if not getattr(self, "tower_streams", True):
             self._main_stream = None
             return self.encode_image(image, use_grid), self.encode_text(text)
@@ -854,17 +788,12 @@ class CLIP(nn.Module):
         self._main_stream = cur
         s_img.wait_stream(cur)
         s_txt.wait_stream(cur)
-        self._in_fork = True
-        try:
-            with torch.cuda.stream(s_img):
-                image_features = self.encode_image(image, use_grid)
-            with torch.cuda.stream(s_txt):
-                text_features = self.encode_text(text)
-        finally:
-            self._in_fork = False
+        with torch.cuda.stream(s_img):
+            image_features = self.encode_image(image, use_grid)
+        with torch.cuda.stream(s_txt):
+            text_features = self.encode_text(text)
         cur.wait_stream(s_img)
         cur.wait_stream(s_txt)
-        self._pending_text = None          # (the join above is behind it)
         image_features.record_stream(cur)
         text_features.record_stream(cur)
         return image_features, text_features

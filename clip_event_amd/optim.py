@@ -81,15 +81,9 @@ class FusedAdam(torch.optim.Optimizer):
         return self.sumsq.sqrt()
 
     @torch.no_grad()
-    def step(self, closure=None, defer_text: bool = False):
-        """clip + Adam.  ``defer_text`` (passed by engine.train_step, which owns the whole step; acted on only with
-        ``CE_DEFER_TEXT_UPDATE=1``): the text tower's share of the update -- 42 % of the parameters, 0.3 ms -- runs on the text
-        tower's stream, where the next step's text forward queues behind it, while the next step's image forward starts on the
-        updated image tower at once (the next ``zero_grad_first_touch`` zero-fills the text tower's gradient segments on that
-        stream too, behind the update that reads them).  Anything else that touches the text tower's parameters first goes
-        through ``model.join_updates()`` (every model / optimiser method does).  OFF by default: measured 12.04-12.17 against
-        12.11-12.16 ms per step -- the GEMM workgroups own their CUs' whole register file and LDS, so the update's
-        waves do not run BESIDE the image forward but between its workgroups, and the step is no shorter."""
+    def step(self, closure=None):
+        """clip + Adam (engine.py:87-95): sum of squares of the whole gradient buffer, then the update with the clip coefficient
+        applied on the fly -- by default in tiles that also leave the blocks' W^T operand copies behind (``ce_adam_step_tiles``)."""
         if closure is not None:
             raise RuntimeError("FusedAdam.step takes no closure")
         self._state()
@@ -126,24 +120,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._moments_stale = True
             m.mark_operands_stale(mirror_fresh=False)
             return
-        side = getattr(m, "_side_streams", None)
-        t0 = m._ranges["text"][0]
-        if (defer_text and side is not None and getattr(m, "tower_streams", True) and not getattr(m, "fp8", False)
-                and 0 < t0 < n and os.environ.get("CE_DEFER_TEXT_UPDATE", "0") == "1"):
-            adam(0, t0, s)
-            cur = torch.cuda.current_stream()
-            side[1].wait_stream(cur)
-            with torch.cuda.stream(side[1]):
-                grid = int(os.environ.get("CE_ADAM_TEXT_GRID", "0"))
-                if grid:
-                    lib().ce_adam_set_grid(c_long(grid))
-                adam(t0, n, stream())
-                if grid:
-                    lib().ce_adam_set_grid(c_long(0))
-                ev = torch.cuda.Event()
-                ev.record(side[1])
-            m._pending_text = ev
-        elif getattr(m, "_adam_tiles_ok", False) and os.environ.get("CE_ADAM_TILES", "1") != "0":
+        if getattr(m, "_adam_tiles_ok", False) and os.environ.get("CE_ADAM_TILES", "1") != "0":
             # the block weights tile by tile, which also writes their W^T operand copies (no transpose pass at the start of the
             # next step); everything else by the chunk table of the first-touch zero-fill (= the complement of the block weights)
             tj, tn_, tt = m._tjobs_bwd
@@ -153,12 +130,9 @@ class FusedAdam(torch.optim.Optimizer):
                                            c_float(self.betas[0]), c_float(self.betas[1]), c_float(self.eps), c_float(self.weight_decay),
                                            c_int(self.step_count), s), "ce_adam_step_tiles")
             m.mark_operands_stale(mirror_fresh=True, wt_fresh=True)
-            if self.sat_poll_every and self.step_count % self.sat_poll_every == 0 and hasattr(m, "poll_stream16_saturation"):
-                m.poll_stream16_saturation()
-            return
         else:
             adam(0, n, s)
-        m.mark_operands_stale(mirror_fresh=True)
+            m.mark_operands_stale(mirror_fresh=True)
         # fp16 streams: look at the clamp counters every few steps, without a synchronisation (the copy started by one poll is
         # examined by the next); raises model.Stream16Saturation
         if self.sat_poll_every and self.step_count % self.sat_poll_every == 0 and hasattr(m, "poll_stream16_saturation"):

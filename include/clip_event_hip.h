@@ -303,9 +303,6 @@ int ce_zero_segments(float* base, const long* table_device, int nchunks, void* s
 /* p_bf16 (nullable): bf16 mirror of the updated parameters, same flat layout (the GEMM operand copies) */
 int ce_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* sumsq, float max_norm,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
-/* Workgroups of the following ce_adam_step launches (0: default).  An update launched beside other kernels can be confined to
- * a few CUs' worth of workgroups. */
-int ce_adam_set_grid(long blocks);
 /* dst[c][r] = src[r][c] (bf16, dense) for a device table of matrices in one launch; tile_start = running
  * count of 64x64 tiles (jobs sorted by it) */
 typedef struct ce_transpose_job {
