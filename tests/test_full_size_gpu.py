@@ -312,3 +312,37 @@ def test_config3_per_rank_full_size(vitb32):
     # rows are independent; the sub-batch's GEMMs may pick other tile heights (same K order) -- bf16 rounding level at most
     print(f"sub-batch features rel {_rel(fi[:32], fi_s):.2e} / {_rel(ft[:32 * K], ft_s):.2e}")
     assert _rel(fi[:32], fi_s) < 2e-3 and _rel(ft[:32 * K], ft_s) < 2e-3
+
+
+def test_full_size_adam_in_tiles_equals_the_flat_kernel(monkeypatch):
+    """ViT-B/32's real parameter set (151 M parameters, block weights 2304 x 768 / 768 x 768 / 3072 x 768 / 768 x 3072 and the
+    512-wide text tower): `ce_adam_step_tiles` against the flat kernel -- masters, both moments and the bf16 mirror bit for bit on
+    every parameter element, every W^T operand copy the transpose of its mirror, after two steps with weight decay (max_norm far
+    above the norm: the clip coefficient is exactly 1 whatever order the norm's float atomics arrived in)."""
+    from oracle import clip_oracle as O
+    from clip_event_amd.model import build_model
+    from clip_event_amd.optim import FusedAdam
+    out = {}
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("CE_ADAM_TILES", tiles)
+        m = build_model(O.init_params(O.VIT_B32, 0)).to(DEV)
+        opt = FusedAdam(m, lr=1e-4, max_norm=1e9, weight_decay=0.01)
+        opt.zero_grad()
+        g = torch.Generator(device=DEV).manual_seed(3)
+        for it in range(2):
+            m._flat_grad.copy_(torch.randn(m._flat_grad.numel(), generator=g, device=DEV) * 0.02)
+            opt.step()
+        torch.cuda.synchronize()
+        if tiles == "1":
+            assert m._wt_fresh
+            for n in m._pmap:
+                if m._is_block_weight(n):
+                    assert torch.equal(m._w16t[n], m._w16[n].t().contiguous()), n
+        live = torch.zeros(m._flat.numel(), dtype=torch.bool, device=DEV)
+        for n, p_ in m._pmap.items():
+            live[m._offsets[n]: m._offsets[n] + p_.numel()] = True
+        out[tiles] = tuple(t[live].clone() for t in (m._flat, opt.m, opt.v, m._flat16))
+        del m, opt
+        torch.cuda.empty_cache()
+    for i, what in enumerate(("masters", "exp_avg", "exp_avg_sq", "bf16 mirror")):
+        assert torch.equal(out["1"][i], out["0"][i]), what
