@@ -1994,6 +1994,32 @@ constexpr bool nt_two_heights(int epi) {
 }
 inline int cu_budget() { return g_cus >= 32 && g_cus <= 256 ? g_cus : 256; }
 inline long nt256_cost(long tiles, int tm) { return ((tiles + cu_budget() - 1) / cu_budget()) * (28 + 10 * tm); }
+// Two tile heights for one persistent launch (gemm_nt160p_kernel<EPI, TM, F8, TS>): n_tall row panels of 32 TM rows, the rest in panels
+// of 32 TS, chosen so that the longest per-workgroup list (tall tiles first, round-robin over G workgroups) is shortest under the
+// launch policy's cost model (32 tm + 48 per tile).  `uniform` = the best single height's cost; true when a split beats it by >=
+// min_gain per cent.
+inline bool two_height_plan(long M, long tn, long G, int TM, long uniform, int min_gain, long& b_tall, long& b_short, int& b_ts) {
+    const long ct = 32 * TM + 48;
+    auto span = [&](long n_tall, int ts, long n_short) {      // cost of the longest list
+        const long T = n_tall * tn, S = n_short * tn, q = T / G, r = T % G;
+        auto shorts = [&](long d) { return d < S ? (S - 1 - d) / G + 1 : 0; };   // short tiles of the workgroup d places behind r
+        const long cs = 32 * ts + 48;
+        long worst = q * ct + shorts(0) * cs;                  // workgroup r: q tall tiles, the most short ones
+        if (r > 0) worst = std::max(worst, (q + 1) * ct + shorts(G - r) * cs);   // workgroup 0: q + 1 tall
+        return worst;
+    };
+    long best = uniform;
+    b_tall = -1; b_short = 0; b_ts = 0;
+    for (int ts = TM - 1; ts >= 1; --ts)
+        for (long n_tall = M / (32 * TM); n_tall >= 1; --n_tall) {
+            const long rest = M - n_tall * 32 * TM;
+            if (rest <= 0) continue;
+            const long n_short = (rest + 32 * ts - 1) / (32 * ts);
+            const long c = span(n_tall, ts, n_short);
+            if (c < best || (c == best && b_tall < 0)) { best = c; b_tall = n_tall; b_short = n_short; b_ts = ts; }
+        }
+    return b_tall > 0 && best * 100 <= uniform * (100 - min_gain);
+}
 inline long nt32_cost(long tiles) {
     const long n = (tiles + 255) / 256;
     return (n / 2) * 146 + (n % 2) * 78;
@@ -2146,32 +2172,16 @@ int launch_nt(NTArgs a, hipStream_t stream) {
                 static const int mixed = getenv("CE_NT_MIXED") ? atoi(getenv("CE_NT_MIXED")) : 1;
                 if (mixed && f == 0 && strip == 0 && a.tile_chunk == 0 && a.M >= 320) {
                     const long G = pgrid, tn = a.tiles_n;
-                    auto span = [&](long n_tall, int ts, long n_short) {      // cost of the longest list
-                        const long T = n_tall * tn, S = n_short * tn, q = T / G, r = T % G;
-                        auto shorts = [&](long d) { return d < S ? (S - 1 - d) / G + 1 : 0; };   // short tiles of the workgroup d places behind r
-                        const long c5 = 32 * 5 + 48, cs = 32 * ts + 48;
-                        long worst = q * c5 + shorts(0) * cs;                  // workgroup r: q tall tiles, the most short ones
-                        if (r > 0) worst = std::max(worst, (q + 1) * c5 + shorts(G - r) * cs);   // workgroup 0: q + 1 tall
-                        return worst;
-                    };
                     long uniform = -1;
                     for (int tm = 5; tm >= 3; --tm) {
                         const long tiles_u = (long)ce_div_up(a.M, 32 * tm) * tn;
                         const long c = ((tiles_u + G - 1) / G) * (32 * tm + 48);
                         if (uniform < 0 || c < uniform) uniform = c;
                     }
-                    long best = uniform, b_tall = -1, b_short = 0;
-                    int b_ts = 0;
-                    for (int ts = 4; ts >= 1; --ts)
-                        for (long n_tall = a.M / 160; n_tall >= 1; --n_tall) {
-                            const long rest = a.M - n_tall * 160;
-                            if (rest <= 0) continue;
-                            const long n_short = (rest + 32 * ts - 1) / (32 * ts);
-                            const long c = span(n_tall, ts, n_short);
-                            if (c < best || (c == best && b_tall < 0)) { best = c; b_tall = n_tall; b_short = n_short; b_ts = ts; }
-                        }
+                    long b_tall, b_short;
+                    int b_ts;
                     static const int min_gain = getenv("CE_NT_MIXED_GAIN") ? atoi(getenv("CE_NT_MIXED_GAIN")) : 3;   // per cent
-                    if (b_tall > 0 && best * 100 <= uniform * (100 - min_gain)) {
+                    if (two_height_plan(a.M, tn, G, 5, uniform, min_gain, b_tall, b_short, b_ts)) {
                         a.tall_panels = (int)b_tall;
                         g_last_tall = (int)b_tall; g_last_ts = b_ts;
                         a.tiles_m = (int)(b_tall + b_short);
@@ -2281,6 +2291,11 @@ int launch_nt_f8(NTArgs a, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160lw_kernel<EPI, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+        if constexpr (nt_two_heights(EPI)) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 4, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
+        }
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt160p_kernel<EPI, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, N4P_LDS_BYTES);
     });
     if (!(a.M >= 1024 && a.N >= 256 && a.K % 128 == 0 && a.K >= 256 && a.N % 8 == 0 && a.lda % 16 == 0 && a.ldb % 16 == 0 &&
@@ -2318,6 +2333,27 @@ int launch_nt_f8(NTArgs a, hipStream_t stream) {
         a.tile_chunk = 0;
         const long tiles = (long)a.tiles_m * a.tiles_n;
         const dim3 grid((unsigned)(tiles < cu_budget() ? tiles : cu_budget()));
+        g_last_tall = g_last_ts = 0;
+        if constexpr (nt_two_heights(EPI)) {       // two tile heights (128-row panels + a shorter tail height), as launch_nt
+            static const int mixed = getenv("CE_NT_MIXED") ? atoi(getenv("CE_NT_MIXED")) : 1;
+            static const int min_gain = getenv("CE_NT_MIXED_GAIN") ? atoi(getenv("CE_NT_MIXED_GAIN")) : 3;
+            long b_tall, b_short;
+            int b_ts;
+            if (mixed && a.M >= 256 && two_height_plan(a.M, a.tiles_n, cu_budget(), 4, bc, min_gain, b_tall, b_short, b_ts)) {
+                a.tall_panels = (int)b_tall;
+                g_last_tall = (int)b_tall; g_last_ts = b_ts;
+                a.tiles_m = (int)(b_tall + b_short);
+                const long tiles2 = (long)a.tiles_m * a.tiles_n;
+                const dim3 grid2((unsigned)(tiles2 < cu_budget() ? tiles2 : cu_budget()));
+                switch (b_ts) {
+                    case 1: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1, 1>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                    case 2: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1, 2>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                    default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1, 3>), grid2, block, N4P_LDS_BYTES, stream, a); break;
+                }
+                CE_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         switch (ptm) {
             case 3: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 3, 1>), grid, block, N4P_LDS_BYTES, stream, a); break;
             default: hipLaunchKernelGGL((gemm_nt160p_kernel<EPI, 4, 1>), grid, block, N4P_LDS_BYTES, stream, a); break;

@@ -992,3 +992,32 @@ def test_gemm_nt_two_tile_heights(M, N, K, plan, dynamic):
     assert _report("two heights colsum", got["colsum"].cpu(), want["colsum"].cpu())[1] < 1e-5      # (float atomics: order)
     acc = (A.float() @ B.float().t()).cpu()
     assert _report("two heights bf16", got["bf16"].float().cpu(), acc.to(torch.bfloat16).float())[1] < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(18464, 1024, 1024), (18464, 4096, 1024), (9000, 2048, 512)])
+def test_gemm_nt_fp8_two_tile_heights(M, N, K):
+    """The e4m3 persistent kernel with two tile heights (128-row panels + a shorter tail height; `launch_nt_fp8_lw`): bit-identical
+    to the one-height launch (CE_NT_MIXED is read once per process, so the one-height result comes from the same kernel family forced
+    through `ce_gemm_nt_fp8_tune`), and the plan the launcher took is a real split at ViT-L/14@336's shapes."""
+    from ctypes import byref, c_int
+    from clip_event_amd import ops, _lib as L
+    rng = np.random.default_rng(M + N + K)
+    a = _randn(rng, M, K).to(torch.bfloat16)
+    b = _randn(rng, N, K, scale=K ** -0.5).to(torch.bfloat16)
+    qa, sa, fa = _q8_ref(a)
+    qb, sb, fb = _q8_ref(b)
+    bias = _randn(rng, N)
+    resid = _randn(rng, M, N)
+    A8, SA, B8, SB = qa.to(DEV), sa.to(DEV), qb.to(DEV), sb.to(DEV)
+    lib = L.lib()
+    got = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BIAS_RESID_F32, bias=bias.to(DEV), resid=resid.to(DEV))
+    tall, ts = c_int(-1), c_int(-1)
+    lib.ce_gemm_nt_last_plan(byref(tall), byref(ts))
+    got16 = ops.gemm_nt_fp8(A8, SA, B8, SB, L.EPI_BF16)
+    torch.cuda.synchronize()
+    print(f"fp8 two heights {M}x{N}x{K}: {tall.value} panels of 128 rows + panels of {32 * ts.value} rows")
+    if M == 18464:
+        assert tall.value > 0 and 1 <= ts.value <= 3, (tall.value, ts.value)
+    ref = (fa @ fb.t()) * sa[:, None] * sb[None, :]
+    assert _report("fp8 two heights bias+resid f32", got.cpu(), ref + bias + resid)[1] < 1e-5
+    assert _report("fp8 two heights bf16", got16.float().cpu(), ref.to(torch.bfloat16).float())[1] < 3e-3
