@@ -438,6 +438,23 @@ __device__ __forceinline__ void store_block(char* dst, const BlockRegs& b, int t
     }
 }
 
+// (block within the sequence, (sample, head)) of this workgroup.  The grid is (blocks per sequence, B H) and workgroups are handed to the
+// eight XCDs round-robin in launch order, x fastest: with the plain decoding the blocks of ONE (sample, head) -- which all stream the same
+// K / V (forward, dQ) or Q / dO (dK / dV) slices -- land on eight different L2s.  Here XCD x owns the (sample, head) pairs congruent to x
+// modulo 8 and walks their blocks one pair after the other, so a pair's slices are fetched into one L2 once.  Bijective when B H is a
+// multiple of 8 (else the plain order).  Speed only, never correctness.  CE_ATTN_XCD=0 (launcher) switches it off.
+__device__ __forceinline__ void long_block_coords(int xcd_order, int& blk, int& bh) {
+    blk = blockIdx.x;
+    bh = blockIdx.y;
+    const int nblk = gridDim.x, nbh = gridDim.y;
+    if (xcd_order && (nbh & 7) == 0) {
+        const int id = blockIdx.y * nblk + blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        bh = (slot / nblk) * 8 + xcd;
+        blk = slot - (slot / nblk) * nblk;
+    }
+}
+
 // NS 16-query strips per wave (a workgroup = 4 waves = 64 NS queries): every K fragment and every transposed V fragment read
 // from LDS serves NS strips.  With one strip per wave the 20 resident waves of a CU each re-read the whole 16 KiB K / V block
 // for 16 queries -- 320 KiB of LDS reads per CU and key block, 2.5 k cycles at the 128 B/clk the LDS delivers, twice the
@@ -449,13 +466,15 @@ __device__ __forceinline__ void store_block(char* dst, const BlockRegs& b, int t
 template <int NS>
 __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ o,
                                                             long ldo, float* __restrict__ lse, int L, int H, int D,
-                                                            int causal, float scale) {
+                                                            int causal, float scale, int xcd_order) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW];
     char* sK = smem;
     char* sV = smem + LB * ROW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
+    int qb, bh_;
+    long_block_coords(xcd_order, qb, bh_);
+    const int b = bh_ / H, h = bh_ - b * H;
     const bf16_t* base = qkv + (long)b * L * ld + h * HD;
     const int li = lane & 15, g = lane >> 4;
     constexpr int QB = LB * NS;                                // queries per workgroup
@@ -609,14 +628,16 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dq_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ dout, long lddo,
                                                                const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                                long lddq, float* __restrict__ bias_grad, float* __restrict__ delta_out,
-                                                               int L, int H, int D, int causal, float scale) {
+                                                               int L, int H, int D, int causal, float scale, int xcd_order) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW + 64 * 4];
     char* sK = smem;
     char* sV = smem + LB * ROW;
     float* csum = reinterpret_cast<float*>(smem + 2 * LB * ROW);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
+    int qb, bh_;
+    long_block_coords(xcd_order, qb, bh_);
+    const int b = bh_ / H, h = bh_ - b * H;
     const bf16_t* base = qkv + (long)b * L * ld + h * HD;
     const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
     const bf16_t* ob = o + (long)b * L * ldo + h * HD;
@@ -749,7 +770,7 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                                 long lddq, float* __restrict__ bias_grad,
                                                                 const float* __restrict__ delta_in, int L, int H, int D,
-                                                                int causal, float scale) {
+                                                                int causal, float scale, int xcd_order) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LB * ROW + (2 * LB + 128) * 4];
     char* sQ = smem;
     char* sDO = sQ + LB * ROW;
@@ -758,7 +779,9 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
     float* csum = sDelta + LB;                                  // [2][64]: dk | dv
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kb = blockIdx.x, b = blockIdx.y / H, h = blockIdx.y - b * H;
+    int kb, bh_;
+    long_block_coords(xcd_order, kb, bh_);
+    const int b = bh_ / H, h = bh_ - b * H;
     const bf16_t* base = qkv + (long)b * L * ld + h * HD;
     const bf16_t* dob = dout + (long)b * L * lddo + h * HD;
     (void)o; (void)ldo;                                         // (delta arrives from the dQ kernel)
@@ -920,6 +943,10 @@ __global__ __launch_bounds__(256) void attn_bwd_long_dkv_kernel(const bf16_t* __
 }
 
 int tiles_for(int L) { return ((L + 31) / 32) * 2; }
+int attn_xcd_order() {          // long_block_coords: XCD-owned (sample, head) pairs (default) or the plain launch order (CE_ATTN_XCD=0)
+    static const int v = getenv("CE_ATTN_XCD") ? atoi(getenv("CE_ATTN_XCD")) : 1;
+    return v;
+}
 
 // Per-stream scratch of the long-sequence backward (delta, [B, H, L] floats: 1.2 MB at ViT-L/14@336, B = 32).  Grow-only; kernels
 // of one stream run in order, so consecutive calls on a stream may share it.  (hipMallocAsync / hipFreeAsync around the two
@@ -964,10 +991,10 @@ extern "C" int ce_attention_fwd(const void* qkv, long ld, void* o, long ldo, flo
         static const int ns = getenv("CE_ATTN_NS_FWD") ? atoi(getenv("CE_ATTN_NS_FWD")) : 1;
         if (ns == 1)
             hipLaunchKernelGGL(attn_fwd_long_kernel<1>, dim3((L + LB - 1) / LB, B * H), dim3(256), 0, sl, (const bf16_t*)qkv, ld,
-                               (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f);
+                               (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f, attn_xcd_order());
         else
             hipLaunchKernelGGL(attn_fwd_long_kernel<2>, dim3((L + 2 * LB - 1) / (2 * LB), B * H), dim3(256), 0, sl, (const bf16_t*)qkv, ld,
-                               (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f);
+                               (bf16_t*)o, ldo, lse, L, H, D, causal, 0.125f, attn_xcd_order());
         CE_LAUNCH_CHECK();
         return 0;
     }
@@ -1012,16 +1039,16 @@ extern "C" int ce_attention_bwd(const void* qkv, long ld, const void* o, long ld
         }
         if (ns == 1)
             hipLaunchKernelGGL(attn_bwd_long_dq_kernel<1>, grid1, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f, attn_xcd_order());
         else
             hipLaunchKernelGGL(attn_bwd_long_dq_kernel<2>, grid2, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f, attn_xcd_order());
         if (nk == 1)
             hipLaunchKernelGGL(attn_bwd_long_dkv_kernel<1>, grid1, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f, attn_xcd_order());
         else
             hipLaunchKernelGGL(attn_bwd_long_dkv_kernel<2>, grid2, dim3(256), 0, sl, (const bf16_t*)qkv, ld, (const bf16_t*)o, ldo,
-                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f);
+                               (const bf16_t*)dout, lddo, lse, (bf16_t*)dqkv, lddq, bias_grad, delta, L, H, D, causal, 0.125f, attn_xcd_order());
         CE_LAUNCH_CHECK();
         return 0;
     }
